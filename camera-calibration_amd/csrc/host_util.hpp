@@ -1,0 +1,13 @@
+// host_util.hpp -- error reporting shared by the host-side sources.
+#pragma once
+#include <cstdarg>
+#include <vector>
+
+namespace ccalib {
+// Records a thread-local message and returns `code` (so call sites can `return set_error(...)`).
+int set_error(int code, const char* fmt, ...);
+
+bool solve_lu(std::vector<double> A, std::vector<double>& b, int n);
+void solve_sym_svd(const std::vector<double>& A, std::vector<double>& b, int n);
+void eig_sym(std::vector<double> A, int n, std::vector<double>& w, std::vector<double>& V);
+}  // namespace ccalib

@@ -1,0 +1,208 @@
+// lm_driver.cpp -- host side of the LM loop: damping, the reduced shared-block solve, acceptance
+// and convergence.  It follows the CvLevMarq state machine of OpenCV 4.1.0
+// (modules/calib3d/src/compat_ptsetreg.cpp: updateAlt / step) as the reference drives it through
+// calibrateCamera (monocular_circle.cpp:93-94) and stereoCalibrate (binocular_chessboard.cpp:152-162):
+//   lambda = 10^lambdaLg10 starting at 1e-3, diag *= 1 + lambda, retry on the same Jacobian with
+//   lambda * 10 when the error grows, lambda / 10 after an accepted step, stop on iteration count or
+//   on |param - prevParam| / |prevParam| < eps taken over ALL parameters (views included).
+// OpenCV solves the full (shared + 6N)^2 system; here each view's 6x6 block is eliminated by the
+// backend (on the GPU) and only the small reduced system is solved on the host.  The two are the
+// same linear system.
+#include <chrono>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "ccalib.h"
+#include "host_util.hpp"
+
+namespace ccalib {
+
+// Gaussian elimination with partial pivoting (cv::solve DECOMP_LU).  A is n x n row-major.
+bool solve_lu(std::vector<double> A, std::vector<double>& b, int n) {
+    for (int i = 0; i < n; i++) {
+        int k = i;
+        for (int j = i + 1; j < n; j++)
+            if (std::fabs(A[j * n + i]) > std::fabs(A[k * n + i])) k = j;
+        if (std::fabs(A[k * n + i]) < DBL_EPSILON * 100) return false;
+        if (k != i) {
+            for (int j = i; j < n; j++) std::swap(A[i * n + j], A[k * n + j]);
+            std::swap(b[i], b[k]);
+        }
+        double d = -1 / A[i * n + i];
+        for (int j = i + 1; j < n; j++) {
+            double alpha = A[j * n + i] * d;
+            for (int c = i + 1; c < n; c++) A[j * n + c] += alpha * A[i * n + c];
+            b[j] += alpha * b[i];
+        }
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        double s = b[i];
+        for (int c = i + 1; c < n; c++) s -= A[i * n + c] * b[c];
+        b[i] = s / A[i * n + i];
+    }
+    return true;
+}
+
+// Symmetric eigen-decomposition by cyclic Jacobi rotations: w descending, rows of V = eigenvectors.
+void eig_sym(std::vector<double> A, int n, std::vector<double>& w, std::vector<double>& V) {
+    V.assign((size_t)n * n, 0.);
+    for (int i = 0; i < n; i++) V[i * n + i] = 1.;
+    for (int sweep = 0; sweep < 100; sweep++) {
+        double off = 0, diag = 0;
+        for (int i = 0; i < n; i++) {
+            diag += A[i * n + i] * A[i * n + i];
+            for (int j = i + 1; j < n; j++) off += A[i * n + j] * A[i * n + j];
+        }
+        if (off <= 1e-60 || off <= 1e-32 * diag) break;
+        for (int p = 0; p < n - 1; p++)
+            for (int q = p + 1; q < n; q++) {
+                double apq = A[p * n + q];
+                if (apq == 0) continue;
+                double th = (A[q * n + q] - A[p * n + p]) / (2 * apq);
+                double t = (th >= 0 ? 1 : -1) / (std::fabs(th) + std::sqrt(th * th + 1));
+                double c = 1 / std::sqrt(t * t + 1), s = t * c;
+                for (int k = 0; k < n; k++) {
+                    double x = A[k * n + p], y = A[k * n + q];
+                    A[k * n + p] = c * x - s * y, A[k * n + q] = s * x + c * y;
+                }
+                for (int k = 0; k < n; k++) {
+                    double x = A[p * n + k], y = A[q * n + k];
+                    A[p * n + k] = c * x - s * y, A[q * n + k] = s * x + c * y;
+                }
+                for (int k = 0; k < n; k++) {
+                    double x = V[p * n + k], y = V[q * n + k];
+                    V[p * n + k] = c * x - s * y, V[q * n + k] = s * x + c * y;
+                }
+            }
+    }
+    w.resize(n);
+    for (int i = 0; i < n; i++) w[i] = A[i * n + i];
+    for (int i = 0; i < n - 1; i++) {
+        int m = i;
+        for (int j = i + 1; j < n; j++)
+            if (w[j] > w[m]) m = j;
+        if (m != i) {
+            std::swap(w[i], w[m]);
+            for (int k = 0; k < n; k++) std::swap(V[i * n + k], V[m * n + k]);
+        }
+    }
+}
+
+// cv::solve DECOMP_SVD on a symmetric matrix: eigen back-substitution, dropping
+// |w| <= 2 eps sum|w| as SVD back-substitution does.
+void solve_sym_svd(const std::vector<double>& A, std::vector<double>& b, int n) {
+    std::vector<double> w, V, x(n, 0.);
+    eig_sym(A, n, w, V);
+    double thr = 0;
+    for (double v : w) thr += std::fabs(v);
+    thr *= DBL_EPSILON * 2;
+    for (int i = 0; i < n; i++) {
+        if (std::fabs(w[i]) <= thr) continue;
+        double s = 0;
+        for (int k = 0; k < n; k++) s += V[i * n + k] * b[k];
+        s /= w[i];
+        for (int k = 0; k < n; k++) x[k] += s * V[i * n + k];
+    }
+    b = x;
+}
+
+}  // namespace ccalib
+
+using namespace ccalib;
+
+extern "C" int ccalib_lm_run(const ccalib_backend* be, void* user, double* shared, const unsigned char* smask,
+                             int term_type, int max_iter, double eps, int solve_method, ccalib_stats* stats) {
+    if (!be || !shared || !smask || be->ns <= 0 || !be->jac || !be->reduce || !be->step_err || !be->commit)
+        return set_error(CCALIB_ERR_ARG, "ccalib_lm_run: incomplete backend");
+    auto t0 = std::chrono::steady_clock::now();
+    const int ns = be->ns;
+    // CvLevMarq::init
+    if (term_type & CCALIB_TERM_COUNT)
+        max_iter = std::min(std::max(max_iter, 1), 1000);
+    else
+        max_iter = 30;
+    if (term_type & CCALIB_TERM_EPS)
+        eps = std::max(eps, 0.);
+    else
+        eps = DBL_EPSILON;
+    int lambdaLg10 = -3, iters = 0, jac_passes = 0, err_passes = 0;
+    const double LOG10 = std::log(10.);
+    auto lam = [&](int lg) { return std::exp(lg * LOG10); };
+
+    std::vector<int> fidx;
+    for (int i = 0; i < ns; i++)
+        if (smask[i]) fidx.push_back(i);
+    const int nf = (int)fidx.size();
+    std::vector<double> prev(ns, 0.), U((size_t)ns * ns), gs(ns), Ssum((size_t)nf * nf), bsum(nf), dsh(nf);
+    double errNorm = 0, prevErrNorm = DBL_MAX, dn2 = 0, pn2 = 0;
+    int rc;
+
+    // one CvLevMarq::step() + the residual pass that follows it
+    auto step_and_eval = [&](double& err_out) -> int {
+        double lambda = lam(lambdaLg10);
+        if ((rc = be->reduce(user, lambda, fidx.data(), nf, Ssum.data(), bsum.data()))) return rc;
+        std::vector<double> S((size_t)nf * nf), b(nf);
+        for (int a = 0; a < nf; a++) {
+            for (int c = 0; c < nf; c++) {
+                int ia = fidx[a], ic = fidx[c];
+                double u = ia <= ic ? U[(size_t)ia * ns + ic] : U[(size_t)ic * ns + ia];  // completeSymm
+                if (a == c) u *= 1. + lambda;
+                S[(size_t)a * nf + c] = u - Ssum[(size_t)a * nf + c];
+            }
+            b[a] = gs[fidx[a]] - bsum[a];
+        }
+        if (nf > 0) {
+            if (solve_method == 0) {
+                if (!solve_lu(S, b, nf)) std::fill(b.begin(), b.end(), 0.);  // cv::solve leaves zeros
+            } else
+                solve_sym_svd(S, b, nf);
+        }
+        for (int i = 0; i < ns; i++) shared[i] = prev[i];
+        for (int a = 0; a < nf; a++) {
+            dsh[a] = b[a];
+            shared[fidx[a]] = prev[fidx[a]] - b[a];
+        }
+        if (be->fixup) be->fixup(user, shared, prev.data());
+        err_passes++;
+        return be->step_err(user, lambda, fidx.data(), nf, dsh.data(), shared, &dn2, &pn2, &err_out);
+    };
+
+    // STARTED -> CALC_J
+    if (be->fixup) be->fixup(user, shared, prev.data());
+    jac_passes++;
+    if ((rc = be->jac(user, shared, lam(lambdaLg10), U.data(), gs.data(), &errNorm))) return rc;
+    for (;;) {
+        // CALC_J: prevParam = param, step
+        prev.assign(shared, shared + ns);
+        if ((rc = be->commit(user))) return rc;
+        prevErrNorm = errNorm;
+        if ((rc = step_and_eval(errNorm))) return rc;
+        // CHECK_ERR
+        while (errNorm > prevErrNorm) {  // a NaN compares false and is accepted, as in CvLevMarq
+            if (++lambdaLg10 > 16) break;
+            if ((rc = step_and_eval(errNorm))) return rc;
+        }
+        lambdaLg10 = std::max(lambdaLg10 - 1, -16);
+        double num = dn2, den = pn2;
+        for (int i = 0; i < ns; i++) {
+            num += (shared[i] - prev[i]) * (shared[i] - prev[i]);
+            den += prev[i] * prev[i];
+        }
+        if (++iters >= max_iter || std::sqrt(num) / std::sqrt(den) < eps) break;
+        if (be->fixup) be->fixup(user, shared, prev.data());
+        jac_passes++;
+        double unused;
+        if ((rc = be->jac(user, shared, lam(lambdaLg10), U.data(), gs.data(), &unused))) return rc;
+    }
+    if (stats) {
+        stats->iters = iters;
+        stats->jac_passes = jac_passes;
+        stats->err_passes = err_passes;
+        stats->lambda_lg10 = lambdaLg10;
+        stats->final_err = errNorm;
+        stats->device_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return CCALIB_OK;
+}

@@ -1,0 +1,684 @@
+// solver.hip -- device-resident calibration problem and the HIP backend of the host LM driver.
+//
+// One ccalib_solver owns the views of one rank: image points (as given: view-major float2),
+// object points (or one shared board), poses, and the per-view normal-equation blocks, all in
+// HBM for the life of the solve.  Each LM pass is a short, fixed sequence of kernel launches on
+// one stream followed by one small device-to-host copy (and, in multi-GPU runs, one all-reduce
+// of the same small buffer).  The passes replace the view/point loops of
+// cvCalibrateCamera2Internal and cvStereoCalibrateImpl (OpenCV 4.1.0 calibration.cpp; reference
+// call sites monocular_circle.cpp:93-94, monocular_chessboard.cpp:315-317,
+// binocular_chessboard.cpp:152-162, binocular_circle.cpp:153-163).
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "ccalib.h"
+#include "host_util.hpp"
+#include "kernels.hpp"
+#include "stereo_kernels.hpp"
+
+using namespace ccalib;
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return set_error(CCALIB_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                             __FILE__, __LINE__);                                                  \
+    } while (0)
+#define NCCL_TRY(expr)                                                                              \
+    do {                                                                                            \
+        ncclResult_t e_ = (expr);                                                                   \
+        if (e_ != ncclSuccess)                                                                      \
+            return set_error(CCALIB_ERR_HIP, "%s failed: %s (%s:%d)", #expr, ncclGetErrorString(e_), \
+                             __FILE__, __LINE__);                                                   \
+    } while (0)
+
+struct ccalib_solver {
+    int device = 0, ncams = 1, nviews = 0, total = 0, maxnp = 0;
+    bool shared_board = false, board_in_lds = false;
+    int board_np = 0;
+    int G = 4, grid_pass = 0, nblk64 = 0, npad = 0;
+    hipStream_t stream = nullptr;
+    float* d_obj = nullptr;
+    int* d_off = nullptr;
+    float2* d_img[2] = {nullptr, nullptr};
+    double *d_pose_prev = nullptr, *d_pose_cur = nullptr;  // camera-0 poses, nviews x 6
+    double* d_pose3 = nullptr;                              // stereo: composed camera-1 poses
+    double* d_cmp = nullptr;                                // stereo: per-view composition Jacobians (SoA)
+    double* d_blk[2] = {nullptr, nullptr};
+    double* d_part = nullptr;
+    size_t part_cap = 0;
+    double* d_red = nullptr;
+    double* h_red = nullptr;  // pinned
+    static constexpr int kRedCap = 4096;
+
+    // parameters
+    bool started = false;
+    double intr[2][18];
+    unsigned char imask[2][18];
+    double aspect[2] = {0, 0};
+    bool same_focal = false;
+    double lr[6] = {0, 0, 0, 0, 0, 0};
+    StereoLR lr_jac;  // relative pose the per-view blocks in HBM were computed at
+    const ModelOps* ops[2] = {nullptr, nullptr};
+    bool rational[2] = {false, false};
+    double last_err = 0;
+
+    // Schur sums cached by the Jacobian pass for the damping the driver announced
+    bool have_cached = false;
+    double cached_lambda = 0;
+    std::vector<double> cachedS;  // kernel-column space, see reduce()
+
+    // multi-GPU
+    ncclComm_t comm = nullptr;
+    ccalib_allreduce_fn cb = nullptr;
+    void* cb_user = nullptr;
+
+    int ns() const { return ncams == 1 ? 18 : 42; }
+    int kcols() const { return ncams == 1 ? ops[0]->NC : 6 + ops[0]->NC + ops[1]->NC; }
+    // kernel column -> index in the shared vector
+    int kcol_to_shared(int k) const {
+        if (ncams == 1) return ops[0]->col(k);
+        if (k < 6) return k;
+        k -= 6;
+        if (k < ops[0]->NC) return 6 + ops[0]->col(k);
+        return 6 + 18 + ops[1]->col(k - ops[0]->NC);
+    }
+};
+
+namespace {
+
+CamParams cam_params(const double* intr18, double aspect) {
+    CamParams cp;
+    cp.fx = intr18[0], cp.fy = intr18[1], cp.cx = intr18[2], cp.cy = intr18[3];
+    for (int i = 0; i < 8; i++) cp.k[i] = intr18[4 + i];
+    cp.aspect = aspect;
+    return cp;
+}
+
+PassArgs pass_args(const ccalib_solver* s, int cam, const double* pose) {
+    PassArgs a;
+    a.img = s->d_img[cam];
+    a.obj = s->d_obj;
+    a.off = s->d_off;
+    a.pose = pose;
+    a.nviews = s->nviews;
+    a.shared_board = s->shared_board;
+    a.board_np = s->board_np;
+    a.board_in_lds = s->board_in_lds;
+    a.G = s->G;
+    return a;
+}
+
+// Sums d_red[0..n) over ranks (if any) and brings it to h_red.
+int finish_reduction(ccalib_solver* s, int n) {
+    if (s->comm) NCCL_TRY(ncclAllReduce(s->d_red, s->d_red, n, ncclDouble, ncclSum, s->comm, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->h_red, s->d_red, sizeof(double) * n, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->cb) {
+        int rc = s->cb(s->cb_user, s->h_red, n);
+        if (rc) return set_error(CCALIB_ERR_HIP, "all-reduce callback failed (%d)", rc);
+    }
+    return CCALIB_OK;
+}
+
+int ensure_part(ccalib_solver* s, size_t n) {
+    if (n <= s->part_cap) return CCALIB_OK;
+    if (s->d_part) HIP_TRY(hipFree(s->d_part));
+    HIP_TRY(hipMalloc(&s->d_part, sizeof(double) * n));
+    s->part_cap = n;
+    return CCALIB_OK;
+}
+
+const double* cam_pose(const ccalib_solver* s, int cam) { return cam == 0 ? s->d_pose_cur : s->d_pose3; }
+
+void current_shared(const ccalib_solver* s, double* shared) {
+    if (s->ncams == 1) {
+        std::memcpy(shared, s->intr[0], sizeof(double) * 18);
+    } else {
+        std::memcpy(shared, s->lr, sizeof(double) * 6);
+        std::memcpy(shared + 6, s->intr[0], sizeof(double) * 18);
+        std::memcpy(shared + 24, s->intr[1], sizeof(double) * 18);
+    }
+}
+void store_shared(ccalib_solver* s, const double* shared) {
+    if (s->ncams == 1) {
+        std::memcpy(s->intr[0], shared, sizeof(double) * 18);
+    } else {
+        std::memcpy(s->lr, shared, sizeof(double) * 6);
+        std::memcpy(s->intr[0], shared + 6, sizeof(double) * 18);
+        std::memcpy(s->intr[1], shared + 24, sizeof(double) * 18);
+    }
+}
+
+// Stereo: camera-1 poses (and, for Jacobian passes, the composition derivatives) for the current
+// camera-0 poses and relative pose.
+int stereo_compose(ccalib_solver* s, bool with_jac) {
+    if (s->ncams != 2) return CCALIB_OK;
+    StereoLR lr;
+    for (int i = 0; i < 6; i++) lr.v[i] = s->lr[i];
+    launch_compose(s->d_pose_cur, lr, s->nviews, s->npad, s->d_pose3, with_jac ? s->d_cmp : nullptr, s->stream);
+    return CCALIB_OK;
+}
+
+// ---- the four backend operations --------------------------------------------------------------
+
+// Launches the Schur-sum kernels for `lambda` and appends their column sums to d_red at `ofs`.
+// Layout appended: upper triangle (kc(kc+1)/2) then right-hand side (kc), kc = kernel columns.
+int enqueue_schur(ccalib_solver* s, double lambda, int ofs) {
+    int kc = s->kcols(), nsum = kc * (kc + 1) / 2 + kc;
+    int rc = ensure_part(s, (size_t)s->nblk64 * nsum);
+    if (rc) return rc;
+    if (s->ncams == 1)
+        s->ops[0]->schur(s->d_blk[0], s->npad, s->nviews, lambda, s->d_part, s->stream);
+    else if (!launch_stereo_schur(s->ops[0]->NC, s->d_blk[0], s->d_blk[1], s->d_cmp, s->lr_jac, s->npad, s->nviews,
+                                  lambda, s->d_part, s->stream))
+        return set_error(CCALIB_ERR_UNSUPPORTED, "stereo column count %d is not built in", s->ops[0]->NC);
+    launch_colsum(s->d_part, s->nblk64, nsum, s->d_red + ofs, s->stream);
+    return CCALIB_OK;
+}
+
+int be_jac(void* user, const double* shared, double lambda_hint, double* U, double* gs, double* err) {
+    ccalib_solver* s = (ccalib_solver*)user;
+    store_shared(s, shared);
+    const int ns = s->ns();
+    std::memset(U, 0, sizeof(double) * ns * ns);
+    std::memset(gs, 0, sizeof(double) * ns);
+    int rc = stereo_compose(s, true);
+    if (rc) return rc;
+    for (int i = 0; i < 6; i++) s->lr_jac.v[i] = s->lr[i];
+    int ofs = 0, cam_ofs[2] = {0, 0};
+    for (int c = 0; c < s->ncams; c++) {
+        const ModelOps* m = s->ops[c];
+        CamParams cp = cam_params(s->intr[c], s->aspect[c]);
+        PassArgs a = pass_args(s, c, cam_pose(s, c));
+        if ((rc = ensure_part(s, (size_t)s->grid_pass * m->NRED_U))) return rc;
+        m->jac_shared(a, cp, s->grid_pass, s->d_part, s->stream);
+        launch_colsum(s->d_part, s->grid_pass, m->NRED_U, s->d_red + ofs, s->stream);
+        m->jac_view(a, cp, s->grid_pass, s->d_blk[c], s->npad, s->stream);
+        cam_ofs[c] = ofs;
+        ofs += m->NRED_U;
+    }
+    int lr_ofs = ofs;
+    if (s->ncams == 2) {
+        // shared-block pieces that involve the relative pose: B^T V3 B (21), B^T ge3 (6), W3 B (NC1 x 6)
+        int n = 27 + 6 * s->ops[1]->NC;
+        if ((rc = ensure_part(s, (size_t)s->nblk64 * n))) return rc;
+        if (!launch_stereo_lr_sums(s->ops[1]->NC, s->d_blk[1], s->d_cmp, s->lr_jac, s->npad, s->nviews, s->d_part, s->stream))
+            return set_error(CCALIB_ERR_UNSUPPORTED, "stereo column count %d is not built in", s->ops[1]->NC);
+        launch_colsum(s->d_part, s->nblk64, n, s->d_red + ofs, s->stream);
+        ofs += n;
+    }
+    int schur_ofs = ofs;
+    int kc = s->kcols(), nsum = kc * (kc + 1) / 2 + kc;
+    if ((rc = enqueue_schur(s, lambda_hint, ofs))) return rc;
+    ofs += nsum;
+    if (ofs > ccalib_solver::kRedCap) return set_error(CCALIB_ERR_STATE, "reduction buffer too small");
+    if ((rc = finish_reduction(s, ofs))) return rc;
+    s->cachedS.assign(s->h_red + schur_ofs, s->h_red + schur_ofs + nsum);
+    s->cached_lambda = lambda_hint;
+    s->have_cached = true;
+
+    double e = 0;
+    for (int c = 0; c < s->ncams; c++) {
+        const ModelOps* m = s->ops[c];
+        const double* r = s->h_red + cam_ofs[c];
+        int base = s->ncams == 1 ? 0 : 6 + 18 * c;
+        int k = 0;
+        for (int i = 0; i < m->NC; i++)
+            for (int j = i; j < m->NC; j++) U[(size_t)(base + m->col(i)) * ns + base + m->col(j)] = r[k++];
+        for (int i = 0; i < m->NC; i++) gs[base + m->col(i)] = r[k++];
+        e += r[k];
+    }
+    if (s->ncams == 2) {
+        const double* r = s->h_red + lr_ofs;
+        int k = 0;
+        for (int i = 0; i < 6; i++)
+            for (int j = i; j < 6; j++) U[(size_t)i * ns + j] = r[k++];
+        for (int i = 0; i < 6; i++) gs[i] = r[k++];
+        const ModelOps* m1 = s->ops[1];
+        for (int i = 0; i < m1->NC; i++)
+            for (int b = 0; b < 6; b++) U[(size_t)b * ns + 24 + m1->col(i)] = r[k++];
+    }
+    *err = e;
+    s->last_err = e;
+    return CCALIB_OK;
+}
+
+int be_reduce(void* user, double lambda, const int* fidx, int nf, double* Ssum, double* bsum) {
+    ccalib_solver* s = (ccalib_solver*)user;
+    int kc = s->kcols(), nsum = kc * (kc + 1) / 2 + kc;
+    if (!(s->have_cached && s->cached_lambda == lambda)) {
+        int rc = enqueue_schur(s, lambda, 0);
+        if (rc) return rc;
+        if ((rc = finish_reduction(s, nsum))) return rc;
+        s->cachedS.assign(s->h_red, s->h_red + nsum);
+        s->cached_lambda = lambda;
+        s->have_cached = true;
+    }
+    // kernel-column space -> the driver's free set
+    std::vector<int> s2k(s->ns(), -1);
+    for (int k = 0; k < kc; k++) s2k[s->kcol_to_shared(k)] = k;
+    auto tri = [kc](int a, int b) { return a * kc - a * (a - 1) / 2 + (b - a); };
+    for (int a = 0; a < nf; a++) {
+        int ka = s2k[fidx[a]];
+        if (ka < 0) return set_error(CCALIB_ERR_STATE, "free parameter %d is not a kernel column", fidx[a]);
+        for (int c = 0; c < nf; c++) {
+            int kb = s2k[fidx[c]];
+            if (kb < 0) return set_error(CCALIB_ERR_STATE, "free parameter %d is not a kernel column", fidx[c]);
+            Ssum[(size_t)a * nf + c] = s->cachedS[ka <= kb ? tri(ka, kb) : tri(kb, ka)];
+        }
+        bsum[a] = s->cachedS[kc * (kc + 1) / 2 + ka];
+    }
+    return CCALIB_OK;
+}
+
+int be_step_err(void* user, double lambda, const int* fidx, int nf, const double* dshared, const double* shared_new,
+                double* dnorm2, double* pnorm2, double* err) {
+    ccalib_solver* s = (ccalib_solver*)user;
+    int rc;
+    std::vector<double> dfull(s->ns(), 0.);
+    for (int a = 0; a < nf; a++) dfull[fidx[a]] = dshared[a];
+    if ((rc = ensure_part(s, (size_t)std::max(s->nblk64 * 2, s->grid_pass)))) return rc;
+    if (s->ncams == 1) {
+        DeltaC dc;
+        for (int k = 0; k < I_NMODEL; k++) dc.v[k] = 0;
+        for (int k = 0; k < s->ops[0]->NC; k++) dc.v[k] = dfull[s->ops[0]->col(k)];
+        s->ops[0]->backsub(s->d_blk[0], s->npad, s->nviews, lambda, dc, s->d_pose_prev, s->d_pose_cur, s->d_part,
+                           s->stream);
+    } else {
+        StereoDelta sd;
+        int kc = s->kcols();
+        for (int k = 0; k < kStereoMaxCols; k++) sd.v[k] = k < kc ? dfull[s->kcol_to_shared(k)] : 0.;
+        if (!launch_stereo_backsub(s->ops[0]->NC, s->d_blk[0], s->d_blk[1], s->d_cmp, s->lr_jac, s->npad, s->nviews,
+                                   lambda, sd, s->d_pose_prev, s->d_pose_cur, s->d_part, s->stream))
+            return set_error(CCALIB_ERR_UNSUPPORTED, "stereo column count %d is not built in", s->ops[0]->NC);
+    }
+    launch_colsum(s->d_part, s->nblk64, 2, s->d_red, s->stream);
+    // residual pass at the trial point
+    store_shared(s, shared_new);
+    if ((rc = stereo_compose(s, false))) return rc;
+    for (int c = 0; c < s->ncams; c++) {
+        CamParams cp = cam_params(s->intr[c], s->aspect[c]);
+        PassArgs a = pass_args(s, c, cam_pose(s, c));
+        launch_err(a, cp, s->rational[c], s->grid_pass, s->d_part, s->stream);
+        launch_colsum(s->d_part, s->grid_pass, 1, s->d_red + 2 + c, s->stream);
+    }
+    if ((rc = finish_reduction(s, 2 + s->ncams))) return rc;
+    *dnorm2 = s->h_red[0];
+    *pnorm2 = s->h_red[1];
+    *err = s->h_red[2] + (s->ncams == 2 ? s->h_red[3] : 0.);
+    s->last_err = *err;
+    s->have_cached = false;
+    return CCALIB_OK;
+}
+
+int be_commit(void* user) {
+    ccalib_solver* s = (ccalib_solver*)user;
+    std::swap(s->d_pose_prev, s->d_pose_cur);  // the next step rewrites every trial pose
+    s->have_cached = s->have_cached;           // the cached sums belong to the committed Jacobian: keep
+    return CCALIB_OK;
+}
+
+void be_fixup(void* user, double* shared, double* prev) {
+    ccalib_solver* s = (ccalib_solver*)user;
+    if (s->ncams == 1) {
+        if (s->aspect[0] != 0) {
+            shared[0] = shared[1] * s->aspect[0];
+            prev[0] = prev[1] * s->aspect[0];
+        }
+        return;
+    }
+    double* ip = shared + 6;
+    double* pp = prev + 6;
+    if (s->same_focal) {
+        ip[18] = ip[0], ip[19] = ip[1];
+        pp[18] = pp[0], pp[19] = pp[1];
+    }
+    for (int c = 0; c < 2; c++)
+        if (s->aspect[c] != 0) {
+            ip[18 * c] = ip[18 * c + 1] * s->aspect[c];
+            pp[18 * c] = pp[18 * c + 1] * s->aspect[c];
+        }
+}
+
+int choose_G(int nviews, int maxnp) {
+    if (const char* e = std::getenv("CCALIB_G")) {
+        int g = std::atoi(e);
+        if (g >= 2 && g <= 64 && (g & (g - 1)) == 0) return g;
+    }
+    // enough wavefronts to fill 256 CUs several times over, then the best lane utilisation
+    int g0 = 2;
+    while (g0 < 64 && (long long)nviews * g0 / 64 < 8192) g0 <<= 1;
+    while (g0 > 2 && g0 > maxnp) g0 >>= 1;
+    int best = g0;
+    double best_u = 0;
+    for (int g = g0; g >= 2 && g >= g0 / 2; g >>= 1) {
+        double u = (double)maxnp / (g * ((maxnp + g - 1) / g));
+        if (u > best_u + 1e-9) best_u = u, best = g;
+    }
+    return best;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ccalib_solver_create(ccalib_solver** out, int device, int ncams, int nviews, const int* npts,
+                         const float* obj_xyz, int shared_board, const float* img1_uv, const float* img2_uv) {
+    if (!out || !npts || !obj_xyz || !img1_uv || nviews < 1 || (ncams != 1 && ncams != 2) || (ncams == 2 && !img2_uv))
+        return set_error(CCALIB_ERR_ARG, "ccalib_solver_create: bad arguments");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return set_error(CCALIB_ERR_NO_DEVICE, "no HIP device is usable (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return set_error(CCALIB_ERR_ARG, "device %d out of range (%d present)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    ccalib_solver* s = new ccalib_solver();
+    s->device = device, s->ncams = ncams, s->nviews = nviews, s->shared_board = shared_board != 0;
+    std::vector<int> off(nviews + 1, 0);
+    for (int i = 0; i < nviews; i++) {
+        if (npts[i] < 4) {
+            delete s;
+            return set_error(CCALIB_ERR_ARG, "view %d has %d points (at least 4 needed)", i, npts[i]);
+        }
+        if (shared_board && npts[i] != npts[0]) {
+            delete s;
+            return set_error(CCALIB_ERR_ARG, "shared_board needs the same point count in every view");
+        }
+        off[i + 1] = off[i] + npts[i];
+        s->maxnp = std::max(s->maxnp, npts[i]);
+    }
+    s->total = off[nviews];
+    s->board_np = shared_board ? npts[0] : 0;
+    s->board_in_lds = shared_board && s->board_np <= board_lds_capacity();
+    s->G = choose_G(nviews, s->maxnp);
+    int per_block = pass_block_size() / s->G;
+    s->grid_pass = (nviews + per_block - 1) / per_block;
+    if (const char* e = std::getenv("CCALIB_GRID")) s->grid_pass = std::max(1, std::min(s->grid_pass, std::atoi(e)));
+    s->nblk64 = (nviews + 63) / 64;
+    s->npad = (nviews + 63) / 64 * 64;
+    HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    size_t nobj = shared_board ? (size_t)3 * s->board_np : (size_t)3 * s->total;
+    HIP_TRY(hipMalloc(&s->d_obj, sizeof(float) * nobj));
+    HIP_TRY(hipMalloc(&s->d_off, sizeof(int) * (nviews + 1)));
+    HIP_TRY(hipMemcpy(s->d_obj, obj_xyz, sizeof(float) * nobj, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_off, off.data(), sizeof(int) * (nviews + 1), hipMemcpyHostToDevice));
+    const float* imgs[2] = {img1_uv, img2_uv};
+    for (int c = 0; c < ncams; c++) {
+        HIP_TRY(hipMalloc(&s->d_img[c], sizeof(float2) * s->total));
+        HIP_TRY(hipMemcpy(s->d_img[c], imgs[c], sizeof(float2) * s->total, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMalloc(&s->d_pose_prev, sizeof(double) * 6 * nviews));
+    HIP_TRY(hipMalloc(&s->d_pose_cur, sizeof(double) * 6 * nviews));
+    HIP_TRY(hipMemset(s->d_pose_prev, 0, sizeof(double) * 6 * nviews));
+    if (ncams == 2) {
+        HIP_TRY(hipMalloc(&s->d_pose3, sizeof(double) * 6 * nviews));
+        HIP_TRY(hipMalloc(&s->d_cmp, sizeof(double) * kCmpRows * s->npad));
+    }
+    HIP_TRY(hipMalloc(&s->d_red, sizeof(double) * ccalib_solver::kRedCap));
+    HIP_TRY(hipHostMalloc(&s->h_red, sizeof(double) * ccalib_solver::kRedCap));
+    *out = s;
+    return CCALIB_OK;
+}
+
+void ccalib_solver_destroy(ccalib_solver* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->comm) ncclCommDestroy(s->comm);
+    (void)hipFree(s->d_obj), (void)hipFree(s->d_off), (void)hipFree(s->d_img[0]), (void)hipFree(s->d_img[1]);
+    (void)hipFree(s->d_pose_prev), (void)hipFree(s->d_pose_cur), (void)hipFree(s->d_pose3), (void)hipFree(s->d_cmp);
+    (void)hipFree(s->d_blk[0]), (void)hipFree(s->d_blk[1]), (void)hipFree(s->d_part), (void)hipFree(s->d_red);
+    if (s->h_red) (void)hipHostFree(s->h_red);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+int ccalib_solver_set_start(ccalib_solver* s, const double* intr, const unsigned char* imask, const double* aspect,
+                            int same_focal, const double* rt, const double* lr) {
+    if (!s || !intr || !imask || !rt || (s->ncams == 2 && !lr)) return set_error(CCALIB_ERR_ARG, "set_start: bad arguments");
+    HIP_TRY(hipSetDevice(s->device));
+    unsigned need = 0;
+    bool asp = false, rat = false;
+    for (int c = 0; c < s->ncams; c++) {
+        std::memcpy(s->intr[c], intr + 18 * c, sizeof(double) * 18);
+        std::memcpy(s->imask[c], imask + 18 * c, 18);
+        s->aspect[c] = aspect ? aspect[c] : 0.;
+        for (int q = 0; q < 18; q++) {
+            if (q >= I_NMODEL && (imask[18 * c + q] || intr[18 * c + q] != 0.))
+                return set_error(CCALIB_ERR_UNSUPPORTED, "thin-prism / tilted coefficients are not built into this library");
+            if (q < I_NMODEL && imask[18 * c + q]) need |= 1u << q;
+        }
+        if (c > 0 && (s->aspect[c] != 0.) != asp)
+            return set_error(CCALIB_ERR_ARG, "both cameras must agree on whether the aspect ratio is fixed");
+        asp = s->aspect[c] != 0.;
+        rat = rat || (need & 0xE00u) || intr[18 * c + 9] != 0. || intr[18 * c + 10] != 0. || intr[18 * c + 11] != 0.;
+    }
+    if (asp && (need & 1u)) return set_error(CCALIB_ERR_ARG, "fx cannot be free when the aspect ratio is fixed");
+    // one column set for both cameras (the flag word applies to both, as in OpenCV)
+    const ModelOps* m = find_model(need, asp, rat);
+    if (!m) return set_error(CCALIB_ERR_UNSUPPORTED, "no kernel column set covers mask 0x%x", need);
+    for (int c = 0; c < s->ncams; c++) {
+        s->rational[c] = rat;
+        if (m != s->ops[c] || !s->d_blk[c]) {
+            if (s->d_blk[c]) HIP_TRY(hipFree(s->d_blk[c]));
+            HIP_TRY(hipMalloc(&s->d_blk[c], sizeof(double) * (size_t)m->NBLK * s->npad));
+        }
+        s->ops[c] = m;
+    }
+    s->same_focal = same_focal != 0;
+    if (lr) std::memcpy(s->lr, lr, sizeof(double) * 6);
+    HIP_TRY(hipMemcpy(s->d_pose_cur, rt, sizeof(double) * 6 * s->nviews, hipMemcpyHostToDevice));
+    s->started = true;
+    s->have_cached = false;
+    return CCALIB_OK;
+}
+
+int ccalib_rccl_unique_id(char id[128]) {
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+    ncclUniqueId u;
+    NCCL_TRY(ncclGetUniqueId(&u));
+    std::memcpy(id, &u, 128);
+    return CCALIB_OK;
+}
+
+int ccalib_solver_use_rccl(ccalib_solver* s, int nranks, int rank, const char unique_id[128]) {
+    if (!s || nranks < 1 || rank < 0 || rank >= nranks) return set_error(CCALIB_ERR_ARG, "use_rccl: bad arguments");
+    HIP_TRY(hipSetDevice(s->device));
+    ncclUniqueId u;
+    std::memcpy(&u, unique_id, 128);
+    NCCL_TRY(ncclCommInitRank(&s->comm, nranks, u, rank));
+    s->cb = nullptr;
+    return CCALIB_OK;
+}
+
+int ccalib_solver_use_callback(ccalib_solver* s, ccalib_allreduce_fn fn, void* user) {
+    if (!s) return set_error(CCALIB_ERR_ARG, "use_callback: null solver");
+    s->cb = fn;
+    s->cb_user = user;
+    return CCALIB_OK;
+}
+
+int ccalib_solver_run(ccalib_solver* s, int term_type, int max_iter, double eps, int solve_method, ccalib_stats* stats) {
+    if (!s || !s->started) return set_error(CCALIB_ERR_STATE, "ccalib_solver_run before ccalib_solver_set_start");
+    HIP_TRY(hipSetDevice(s->device));
+    ccalib_backend be;
+    be.ns = s->ns();
+    be.jac = be_jac, be.reduce = be_reduce, be.step_err = be_step_err, be.commit = be_commit, be.fixup = be_fixup;
+    double shared[42];
+    unsigned char smask[42];
+    current_shared(s, shared);
+    if (s->ncams == 1)
+        std::memcpy(smask, s->imask[0], 18);
+    else {
+        std::memset(smask, 1, 6);
+        std::memcpy(smask + 6, s->imask[0], 18);
+        std::memcpy(smask + 24, s->imask[1], 18);
+    }
+    int rc = ccalib_lm_run(&be, s, shared, smask, term_type, max_iter, eps, solve_method, stats);
+    store_shared(s, shared);
+    return rc;
+}
+
+int ccalib_solver_get(ccalib_solver* s, double* intr, double* rt, double* lr, double* err) {
+    if (!s || !s->started) return set_error(CCALIB_ERR_STATE, "ccalib_solver_get before set_start");
+    HIP_TRY(hipSetDevice(s->device));
+    if (intr)
+        for (int c = 0; c < s->ncams; c++) std::memcpy(intr + 18 * c, s->intr[c], sizeof(double) * 18);
+    if (rt) {
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        HIP_TRY(hipMemcpy(rt, s->d_pose_cur, sizeof(double) * 6 * s->nviews, hipMemcpyDeviceToHost));
+    }
+    if (lr) std::memcpy(lr, s->lr, sizeof(double) * 6);
+    if (err) *err = s->last_err;
+    return CCALIB_OK;
+}
+
+int ccalib_solver_num_shared(ccalib_solver* s, int* ns) {
+    if (!s || !ns) return set_error(CCALIB_ERR_ARG, "num_shared: bad arguments");
+    *ns = s->ns();
+    return CCALIB_OK;
+}
+
+int ccalib_solver_eval_error(ccalib_solver* s, double* err) {
+    if (!s || !s->started || !err) return set_error(CCALIB_ERR_STATE, "eval_error before set_start");
+    HIP_TRY(hipSetDevice(s->device));
+    int rc;
+    if ((rc = ensure_part(s, s->grid_pass))) return rc;
+    if ((rc = stereo_compose(s, false))) return rc;
+    for (int c = 0; c < s->ncams; c++) {
+        CamParams cp = cam_params(s->intr[c], s->aspect[c]);
+        if (s->aspect[c] != 0) cp.fx = cp.fy * s->aspect[c];
+        PassArgs a = pass_args(s, c, cam_pose(s, c));
+        launch_err(a, cp, s->rational[c], s->grid_pass, s->d_part, s->stream);
+        launch_colsum(s->d_part, s->grid_pass, 1, s->d_red + c, s->stream);
+    }
+    if ((rc = finish_reduction(s, s->ncams))) return rc;
+    *err = s->h_red[0] + (s->ncams == 2 ? s->h_red[1] : 0.);
+    return CCALIB_OK;
+}
+
+int ccalib_solver_eval_jacobian(ccalib_solver* s, double* U, double* gs, double* err) {
+    if (!s || !s->started || !U || !gs || !err) return set_error(CCALIB_ERR_STATE, "eval_jacobian before set_start");
+    HIP_TRY(hipSetDevice(s->device));
+    double shared[42], prev[42] = {0};
+    current_shared(s, shared);
+    be_fixup(s, shared, prev);
+    return be_jac(s, shared, 1e-3, U, gs, err);
+}
+
+int ccalib_solver_fetch_blocks(ccalib_solver* s, double* V, double* W, double* ge) {
+    if (!s || !s->started || s->ncams != 1) return set_error(CCALIB_ERR_STATE, "fetch_blocks: mono solver after a Jacobian pass");
+    HIP_TRY(hipSetDevice(s->device));
+    const ModelOps* m = s->ops[0];
+    std::vector<double> h((size_t)m->NBLK * s->npad);
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipMemcpy(h.data(), s->d_blk[0], sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+    const int ns = 18;
+    for (int v = 0; v < s->nviews; v++) {
+        int k = 0;
+        for (int a = 0; a < 6; a++)
+            for (int b = a; b < 6; b++, k++) V[(size_t)v * 36 + a * 6 + b] = V[(size_t)v * 36 + b * 6 + a] = h[(size_t)k * s->npad + v];
+        for (int a = 0; a < 6; a++) ge[(size_t)v * 6 + a] = h[(size_t)(21 + a) * s->npad + v];
+        for (int i = 0; i < ns * 6; i++) W[(size_t)v * ns * 6 + i] = 0;
+        for (int i = 0; i < m->NC; i++)
+            for (int b = 0; b < 6; b++) W[((size_t)v * ns + m->col(i)) * 6 + b] = h[(size_t)(27 + 6 * i + b) * s->npad + v];
+    }
+    return CCALIB_OK;
+}
+
+int ccalib_solver_reduce(ccalib_solver* s, double lambda, double* Ssum, double* bsum) {
+    if (!s || !s->started) return set_error(CCALIB_ERR_STATE, "reduce before set_start");
+    HIP_TRY(hipSetDevice(s->device));
+    // free set = every kernel column, reported in shared-vector order
+    int kc = s->kcols();
+    std::vector<int> fidx;
+    for (int i = 0; i < s->ns(); i++)
+        for (int k = 0; k < kc; k++)
+            if (s->kcol_to_shared(k) == i) fidx.push_back(i);
+    s->have_cached = false;
+    return be_reduce(s, lambda, fidx.data(), (int)fidx.size(), Ssum, bsum);
+}
+
+int ccalib_solver_time_jacobian(ccalib_solver* s, int reps, double* ms_per_pass) {
+    if (!s || !s->started || reps < 1 || !ms_per_pass) return set_error(CCALIB_ERR_STATE, "time_jacobian: bad state");
+    HIP_TRY(hipSetDevice(s->device));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    int rc = ensure_part(s, (size_t)s->grid_pass * 128);
+    if (rc) return rc;
+    if ((rc = stereo_compose(s, true))) return rc;
+    auto pass = [&]() {
+        for (int c = 0; c < s->ncams; c++) {
+            const ModelOps* m = s->ops[c];
+            CamParams cp = cam_params(s->intr[c], s->aspect[c]);
+            PassArgs a = pass_args(s, c, cam_pose(s, c));
+            m->jac_shared(a, cp, s->grid_pass, s->d_part, s->stream);
+            m->jac_view(a, cp, s->grid_pass, s->d_blk[c], s->npad, s->stream);
+        }
+    };
+    pass();  // warm-up
+    HIP_TRY(hipEventRecord(e0, s->stream));
+    for (int i = 0; i < reps; i++) pass();
+    HIP_TRY(hipEventRecord(e1, s->stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *ms_per_pass = ms / reps;
+    (void)hipEventDestroy(e0), (void)hipEventDestroy(e1);
+    return CCALIB_OK;
+}
+
+int ccalib_reprojection_error(int nviews, const int* npts, const float* obj_xyz, const float* img_uv, const double* K,
+                              const double* dist, int ndist, const double* rvecs, const double* tvecs, float* proj_uv,
+                              double* per_view_rms, double* total_rms) {
+    if (nviews < 1 || !npts || !obj_xyz || !img_uv || !K || !rvecs || !tvecs || ndist < 0 || ndist > 14 || (ndist && !dist))
+        return set_error(CCALIB_ERR_ARG, "reprojection_error: bad arguments");
+    for (int i = 8; i < ndist; i++)
+        if (dist[i] != 0.) return set_error(CCALIB_ERR_UNSUPPORTED, "thin-prism / tilted coefficients are not built into this library");
+    ccalib_solver* s = nullptr;
+    int rc = ccalib_solver_create(&s, 0, 1, nviews, npts, obj_xyz, 0, img_uv, nullptr);
+    if (rc) return rc;
+    struct Guard {
+        ccalib_solver* s;
+        float2* proj = nullptr;
+        double* verr = nullptr;
+        ~Guard() {
+            (void)hipFree(proj), (void)hipFree(verr);
+            ccalib_solver_destroy(s);
+        }
+    } g{s};
+    std::vector<double> rt((size_t)6 * nviews);
+    for (int i = 0; i < nviews; i++) {
+        std::memcpy(&rt[6 * (size_t)i], rvecs + 3 * i, 3 * sizeof(double));
+        std::memcpy(&rt[6 * (size_t)i + 3], tvecs + 3 * i, 3 * sizeof(double));
+    }
+    HIP_TRY(hipMemcpy(s->d_pose_cur, rt.data(), sizeof(double) * rt.size(), hipMemcpyHostToDevice));
+    double intr[18] = {K[0], K[4], K[2], K[5]};
+    for (int i = 0; i < ndist && i < 8; i++) intr[4 + i] = dist[i];
+    CamParams cp = cam_params(intr, 0.);
+    bool rational = intr[9] != 0. || intr[10] != 0. || intr[11] != 0.;
+    if (proj_uv) HIP_TRY(hipMalloc(&g.proj, sizeof(float2) * s->total));
+    HIP_TRY(hipMalloc(&g.verr, sizeof(double) * nviews));
+    launch_reproj(pass_args(s, 0, s->d_pose_cur), cp, rational, s->grid_pass, g.proj, g.verr, s->stream);
+    std::vector<double> verr(nviews);
+    HIP_TRY(hipMemcpyAsync(verr.data(), g.verr, sizeof(double) * nviews, hipMemcpyDeviceToHost, s->stream));
+    if (proj_uv) HIP_TRY(hipMemcpyAsync(proj_uv, g.proj, sizeof(float2) * s->total, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    double tot = 0;
+    for (int i = 0; i < nviews; i++) {
+        tot += verr[i];
+        if (per_view_rms) per_view_rms[i] = std::sqrt(verr[i] / npts[i]);
+    }
+    if (total_rms) *total_rms = std::sqrt(tot / s->total);
+    return CCALIB_OK;
+}
+
+}  // extern "C"

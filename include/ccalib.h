@@ -1,0 +1,236 @@
+/*
+ * ccalib.h -- C ABI of the MI355X-native calibration core (libccalib.so).
+ *
+ * Drop-in boundary for the Levenberg-Marquardt path that the reference reaches through
+ * OpenCV 4.1.0:
+ *   cv::calibrateCamera     /root/reference/monocular_circle.cpp:93-94
+ *   cv::calibrateCameraRO   /root/reference/monocular_chessboard.cpp:315-317 (iFixedPoint = -1)
+ *   cv::stereoCalibrate     /root/reference/binocular_chessboard.cpp:152-162,
+ *                           /root/reference/binocular_circle.cpp:153-163
+ *   cv::projectPoints       /root/reference/monocular_circle.cpp:18-19 (RMS re-check)
+ *   cv::initCameraMatrix2D  /root/reference/binocular_chessboard.cpp:147-148
+ *
+ * Plain pointers and sizes only; every function returns a status code and never throws.
+ * ccalib_last_error() returns a thread-local message for the last non-zero status.
+ * The library computes on the GPU only: there is no CPU fallback, and every compute entry
+ * point fails with CCALIB_ERR_NO_DEVICE when no HIP device is usable.
+ *
+ * Two levels:
+ *   whole-call  (ccalib_calibrate_camera, ccalib_stereo_calibrate, ...): what an FFI binding of
+ *               the cv:: functions above would call;
+ *   solver      (ccalib_solver_*): the device-resident problem the host LM driver steps; it is
+ *               what bench.py times (inputs already in HBM) and what multi-GPU runs shard.
+ */
+#ifndef CCALIB_H
+#define CCALIB_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status ---------------------------------------------------------------------------- */
+enum {
+    CCALIB_OK = 0,
+    CCALIB_ERR_ARG = 1,         /* bad argument (the cases where OpenCV raises cv::Exception) */
+    CCALIB_ERR_HIP = 2,         /* a HIP / RCCL call failed                                   */
+    CCALIB_ERR_NO_DEVICE = 3,   /* no usable GPU                                              */
+    CCALIB_ERR_UNSUPPORTED = 4, /* flag combination outside this build (tilted / thin-prism)  */
+    CCALIB_ERR_STATE = 5,       /* call order violated                                        */
+    CCALIB_ERR_NUMERIC = 6      /* singular reduced system                                    */
+};
+const char* ccalib_last_error(void);
+const char* ccalib_version(void);
+
+/* ---- flag and criteria values: the integers of OpenCV 4.1.0 calib3d.hpp ------------------ */
+enum {
+    CCALIB_USE_INTRINSIC_GUESS = 0x00001,
+    CCALIB_FIX_ASPECT_RATIO = 0x00002,
+    CCALIB_FIX_PRINCIPAL_POINT = 0x00004,
+    CCALIB_ZERO_TANGENT_DIST = 0x00008,
+    CCALIB_FIX_FOCAL_LENGTH = 0x00010,
+    CCALIB_FIX_K1 = 0x00020,
+    CCALIB_FIX_K2 = 0x00040,
+    CCALIB_FIX_K3 = 0x00080,
+    CCALIB_FIX_INTRINSIC = 0x00100,
+    CCALIB_SAME_FOCAL_LENGTH = 0x00200,
+    CCALIB_FIX_K4 = 0x00800,
+    CCALIB_FIX_K5 = 0x01000,
+    CCALIB_FIX_K6 = 0x02000,
+    CCALIB_RATIONAL_MODEL = 0x04000,
+    CCALIB_THIN_PRISM_MODEL = 0x08000,
+    CCALIB_FIX_S1_S2_S3_S4 = 0x10000,
+    CCALIB_USE_LU = (1 << 17),
+    CCALIB_TILTED_MODEL = 0x40000,
+    CCALIB_FIX_TAUX_TAUY = 0x80000,
+    CCALIB_USE_QR = 0x100000,
+    CCALIB_FIX_TANGENT_DIST = 0x200000,
+    CCALIB_USE_EXTRINSIC_GUESS = (1 << 22)
+};
+enum { CCALIB_TERM_COUNT = 1, CCALIB_TERM_EPS = 2 };
+
+typedef struct {
+    int iters;          /* accepted LM iterations (CvLevMarq::iters)                    */
+    int jac_passes;     /* passes over all points that evaluated residuals + Jacobians  */
+    int err_passes;     /* passes that evaluated residuals only                         */
+    int lambda_lg10;    /* final damping exponent                                       */
+    double final_err;   /* sum of squared residuals at the returned parameters          */
+    double device_ms;   /* wall time spent inside the LM loop (host clock)              */
+} ccalib_stats;
+
+/* ---- whole-call level ------------------------------------------------------------------- */
+
+/*
+ * cv::calibrateCamera / cv::calibrateCameraRO(iFixedPoint = -1)
+ * (monocular_circle.cpp:93-94, monocular_chessboard.cpp:315-317).
+ *   npts[nviews]          points per view (>= 4 each)
+ *   obj_xyz               sum(npts) x 3 floats (Point3f), view after view
+ *   img_uv                sum(npts) x 2 floats (Point2f)
+ *   K[9]                  in/out 3x3 row-major.  Read when USE_INTRINSIC_GUESS or FIX_ASPECT_RATIO
+ *                         is set (pass identity for "empty", as OpenCV substitutes eye()).
+ *   dist[ndist]           in/out, ndist in {4,5,8,12,14}; read only with USE_INTRINSIC_GUESS
+ *   rvecs, tvecs          out, nviews x 3 each
+ *   init_rt               optional nviews x 6 starting poses (r|t); NULL runs the per-view
+ *                         pose initialisation OpenCV performs
+ *   rms                   out, sqrt(sum err^2 / sum npts)
+ */
+int ccalib_calibrate_camera(int nviews, const int* npts, const float* obj_xyz, const float* img_uv,
+                            int width, int height, double* K, double* dist, int ndist,
+                            double* rvecs, double* tvecs, int flags, int term_type, int max_iter,
+                            double eps, const double* init_rt, double* rms, ccalib_stats* stats);
+
+/*
+ * cv::stereoCalibrate (binocular_chessboard.cpp:152-162, binocular_circle.cpp:153-163).
+ *   K1,K2 in/out 3x3; dist1,dist2 in/out 14 doubles each; R 3x3, T 3, E 3x3, F 3x3 out.
+ *   init_rt (nviews x 6 camera-0 poses) and init_lr (6: om_LR|T_LR) are optional starts.
+ *   rt_out optional nviews x 6 refined camera-0 poses.
+ *   rms = sqrt(sum err^2 / (2 * sum npts)).
+ */
+int ccalib_stereo_calibrate(int nviews, const int* npts, const float* obj_xyz, const float* img1_uv,
+                            const float* img2_uv, double* K1, double* dist1, double* K2,
+                            double* dist2, int width, int height, double* R, double* T, double* E,
+                            double* F, int flags, int term_type, int max_iter, double eps,
+                            const double* init_rt, const double* init_lr, double* rt_out,
+                            double* rms, ccalib_stats* stats);
+
+/*
+ * cv::projectPoints over many views + the RMS the reference recomputes from it
+ * (monocular_circle.cpp:5-29).  proj_uv (optional) receives sum(npts) x 2 floats,
+ * per_view_rms (optional) nviews doubles, total_rms the global figure.
+ */
+int ccalib_reprojection_error(int nviews, const int* npts, const float* obj_xyz, const float* img_uv,
+                              const double* K, const double* dist, int ndist, const double* rvecs,
+                              const double* tvecs, float* proj_uv, double* per_view_rms,
+                              double* total_rms);
+
+/* cv::initCameraMatrix2D (binocular_chessboard.cpp:147-148).  K out, 3x3. */
+int ccalib_init_camera_matrix_2d(int nviews, const int* npts, const float* obj_xyz,
+                                 const float* img_uv, int width, int height, double aspect,
+                                 double* K);
+
+/* ---- solver level: device-resident problem + host LM driver ------------------------------ */
+typedef struct ccalib_solver ccalib_solver;
+
+/*
+ * Creates a problem on HIP device `device` and uploads the points (float -> kept as float in HBM,
+ * widened in registers).  ncams is 1 (calibrateCamera) or 2 (stereoCalibrate); img2_uv is NULL
+ * for ncams == 1.  If every view has the same object points, pass shared_board = 1 and only the
+ * first view's npts[0] x 3 floats in obj_xyz: the board then lives in LDS instead of HBM.
+ * In a multi-GPU run every rank creates a solver over ITS OWN views.
+ */
+int ccalib_solver_create(ccalib_solver** out, int device, int ncams, int nviews, const int* npts,
+                         const float* obj_xyz, int shared_board, const float* img1_uv,
+                         const float* img2_uv);
+void ccalib_solver_destroy(ccalib_solver* s);
+
+/*
+ * Sets the starting point and the free-parameter set.
+ *   intr      ncams x 18 doubles: fx fy cx cy k1 k2 p1 p2 k3 k4 k5 k6 s1 s2 s3 s4 taux tauy
+ *   imask     ncams x 18 bytes, 1 = optimised (entries 12..17 must be 0)
+ *   aspect    ncams doubles; non-zero ties fx = fy * aspect (CALIB_FIX_ASPECT_RATIO)
+ *   same_focal   stereo only: copy fx,fy of camera 0 into camera 1 before every pass
+ *   rt        nviews x 6 poses of camera 0;  lr  6 doubles (stereo; NULL for mono)
+ */
+int ccalib_solver_set_start(ccalib_solver* s, const double* intr, const unsigned char* imask,
+                            const double* aspect, int same_focal, const double* rt,
+                            const double* lr);
+
+/*
+ * Joins a multi-GPU run: after this call every reduction the LM loop needs (the shared normal-
+ * equation block, its right-hand side and three scalars per pass) is summed over all ranks.
+ * Exactly one of the two forms is used:
+ *   ccalib_solver_use_rccl      in-stream ncclAllReduce over a communicator built from `unique_id`
+ *                               (128 bytes from ccalib_rccl_unique_id on rank 0, shared by the
+ *                               caller, e.g. through torch.distributed)
+ *   ccalib_solver_use_callback  host callback, called with a host buffer to be summed in place
+ */
+int ccalib_rccl_unique_id(char id[128]);
+int ccalib_solver_use_rccl(ccalib_solver* s, int nranks, int rank, const char unique_id[128]);
+typedef int (*ccalib_allreduce_fn)(void* user, double* buf, int n);
+int ccalib_solver_use_callback(ccalib_solver* s, ccalib_allreduce_fn fn, void* user);
+
+/*
+ * Runs the CvLevMarq state machine (damping, reduced solve, convergence on the host; passes on
+ * the GPU) until done.  solve_method: 0 LU (CALIB_USE_LU), 1 eigen/SVD (OpenCV's default).
+ * total_points is the GLOBAL point count (all ranks) used for the RMS; pass 0 for "this rank's".
+ * May be called again to continue (bench.py runs a fixed number of iterations with eps = 0).
+ */
+int ccalib_solver_run(ccalib_solver* s, int term_type, int max_iter, double eps, int solve_method,
+                      ccalib_stats* stats);
+
+/* Results: intr ncams x 18, rt nviews x 6, lr 6 (NULL ok), err = sum of squared residuals. */
+int ccalib_solver_get(ccalib_solver* s, double* intr, double* rt, double* lr, double* err);
+
+/*
+ * Single passes, exposed so that tests can check each kernel against the oracle block by block
+ * and so that bench.py can time the dominant kernel alone.
+ *   eval_error     sum of squared residuals at the current parameters
+ *   eval_jacobian  fills the per-view blocks in HBM; returns the shared block U (ns x ns, upper
+ *                  triangle, ns = number of free shared parameters), its gradient gs and err
+ *   fetch_blocks   copies per-view V (nviews x 36), W (nviews x ns x 6), ge (nviews x 6) to host
+ *   reduce         Schur sums for damping lambda: Ssum = sum_i W_i V_i'^-1 W_i^T (ns x ns),
+ *                  bsum = sum_i W_i V_i'^-1 ge_i
+ *   time_jacobian  runs the Jacobian pass `reps` times back to back and returns the mean
+ *                  duration of one pass in ms, measured with HIP events on the solver's stream
+ */
+int ccalib_solver_num_shared(ccalib_solver* s, int* ns);
+int ccalib_solver_eval_error(ccalib_solver* s, double* err);
+int ccalib_solver_eval_jacobian(ccalib_solver* s, double* U, double* gs, double* err);
+int ccalib_solver_fetch_blocks(ccalib_solver* s, double* V, double* W, double* ge);
+int ccalib_solver_reduce(ccalib_solver* s, double lambda, double* Ssum, double* bsum);
+int ccalib_solver_time_jacobian(ccalib_solver* s, int reps, double* ms_per_pass);
+
+/*
+ * The host LM driver over a caller-supplied backend: the same state machine ccalib_solver_run
+ * uses, with the device passes replaced by function pointers.  This is the seam between the
+ * driver and the kernels; tests drive it with a CPU backend to check sharded runs without a GPU.
+ * All backend outputs must already be summed over ranks.
+ *   jac       Jacobian pass at (shared, trial poses): U (ns x ns, upper triangle), gs (ns), err.
+ *             lambda_hint is the damping the next reduce() will ask for, so a backend may
+ *             compute those sums in the same pass
+ *   reduce    Schur sums for lambda over the free shared set `fidx` (nf indices into shared):
+ *             Ssum (nf x nf, symmetric) = sum_i W_i V_i'^-1 W_i^T,  bsum (nf) = sum_i W_i V_i'^-1 ge_i
+ *   step_err  trial poses = committed poses - V'^-1 (ge - W^T dshared) for every view, then the
+ *             residual pass at (shared_new, trial poses); returns sum |delta_e|^2,
+ *             sum |committed pose|^2 and the new sum of squared residuals
+ *   commit    trial poses become the committed poses
+ *   fixup     called before every pass with the current and previous shared vectors so that ties
+ *             between parameters (fixed aspect ratio, same focal length) can be enforced; may be NULL
+ */
+typedef struct {
+    int ns; /* shared parameter count (18 mono, 42 stereo) */
+    int (*jac)(void* user, const double* shared, double lambda_hint, double* U, double* gs, double* err);
+    int (*reduce)(void* user, double lambda, const int* fidx, int nf, double* Ssum, double* bsum);
+    int (*step_err)(void* user, double lambda, const int* fidx, int nf, const double* dshared,
+                    const double* shared_new, double* dnorm2, double* pnorm2, double* err);
+    int (*commit)(void* user);
+    void (*fixup)(void* user, double* shared, double* prev_shared);
+} ccalib_backend;
+int ccalib_lm_run(const ccalib_backend* be, void* user, double* shared, const unsigned char* smask,
+                  int term_type, int max_iter, double eps, int solve_method, ccalib_stats* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

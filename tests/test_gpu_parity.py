@@ -1,0 +1,266 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle.
+
+Tolerances are BASELINE.json's: RMS, intrinsics and distortion within 1e-6
+relative, extrinsics within 1e-6 rad / unit, iteration count +-1.  The oracle
+restates OpenCV 4.1.0 and is itself unpinned against a real OpenCV (none is
+installed); see tests/test_oracle.py for what pins it instead.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+EPS = float(np.finfo(np.float64).eps)
+REL = 1e-6
+
+
+def _close_params(got, ref, pose_tol=1e-6):
+    assert abs(got["rms"] - ref["rms"]) <= REL * ref["rms"], (got["rms"], ref["rms"])
+    assert np.allclose(got["K"], ref["K"], rtol=REL, atol=1e-9)
+    assert np.allclose(got["dist"], ref["dist"], rtol=REL, atol=1e-9)
+    assert np.abs(got["rvecs"] - ref["rvecs"]).max() < pose_tol
+    assert np.abs(got["tvecs"] - ref["tvecs"]).max() < pose_tol * max(1.0, np.abs(ref["tvecs"]).max())
+
+
+def _start(pkg, synth, ms, flags=0, jitter=1.0):
+    cam = ms.cam
+    K = np.array([[cam.fx * 0.97, 0, cam.cx + 3], [0, cam.fy * 0.98, cam.cy - 2], [0, 0, 1.0]])
+    d = cam.dist(5) * 0.8
+    intr, mask, aspect = pkg.mono_start(K, d, flags)
+    rt = synth.perturbed_poses(ms.rvec, ms.tvec, 99, rot_sigma=0.01 * jitter, trans_sigma=3.0 * jitter)
+    return intr, mask, aspect, rt
+
+
+@pytest.mark.parametrize("flags_name", ["zero", "aspect", "rational6"])
+def test_jacobian_blocks_match_oracle(pkg, orc, synth, flags_name):
+    flags = {"zero": 0, "aspect": pkg.CALIB_FIX_ASPECT_RATIO,
+             "rational6": (pkg.CALIB_FIX_ASPECT_RATIO | pkg.CALIB_ZERO_TANGENT_DIST | pkg.CALIB_RATIONAL_MODEL |
+                           pkg.CALIB_FIX_K3 | pkg.CALIB_FIX_K4 | pkg.CALIB_FIX_K5)}[flags_name]
+    obj = synth.chessboard(9, 6, 25.0)
+    ms = synth.make_views(obj, 37, 7)
+    intr, mask, aspect, rt = _start(pkg, synth, ms, flags)
+    if flags_name == "rational6":
+        intr[11] = 0.03  # k6 away from zero so the rational branch is exercised
+    if aspect:
+        intr[0] = intr[1] * aspect
+    s = pkg.Solver(obj, ms.img)
+    s.set_start(intr, mask, rt, aspect=[aspect])
+    U, gs, err = s.eval_jacobian()
+    V, W, ge = s.fetch_blocks()
+    free = np.flatnonzero(mask)
+    ref = orc.mono_blocks(obj, ms.img, intr, aspect, rt, free)
+    assert abs(err - ref["err"]) < 1e-11 * ref["err"]
+    assert abs(s.eval_error() - ref["err"]) < 1e-11 * ref["err"]
+    Uf = np.triu(U[np.ix_(free, free)])
+    scale = np.sqrt(np.outer(np.diag(ref["U"]), np.diag(ref["U"])))
+    assert np.abs(Uf - np.triu(ref["U"])).max() / 1.0 <= 1e-10 * scale.max()
+    assert np.all(np.abs(Uf - np.triu(ref["U"])) <= 1e-10 * scale + 1e-30)
+    assert np.allclose(gs[free], ref["gc"], rtol=1e-9, atol=1e-9 * np.abs(ref["gc"]).max())
+    assert np.allclose(V, ref["V"], rtol=1e-10, atol=1e-10 * np.abs(ref["V"]).max())
+    assert np.allclose(ge, ref["ge"], rtol=1e-9, atol=1e-9 * np.abs(ref["ge"]).max())
+    assert np.allclose(W[:, free, :], ref["W"], rtol=1e-9, atol=1e-10 * np.abs(ref["W"]).max())
+    # Schur sums for one damping value, against the same algebra in numpy on the oracle's blocks
+    lam = 1e-3
+    Sref = np.zeros((len(free), len(free)))
+    bref = np.zeros(len(free))
+    for i in range(ms.img.shape[0]):
+        Vd = ref["V"][i] + lam * np.diag(np.diag(ref["V"][i]))
+        Y = np.linalg.solve(Vd, ref["W"][i].T)
+        Sref += ref["W"][i] @ Y
+        bref += Y.T @ ref["ge"][i]
+    S, b = s.reduce(lam, len(free)) if True else (None, None)
+    # reduce() reports every kernel column; the free ones are a subset in the same order
+    s.close()
+    kcols = {"zero": [0, 1, 2, 3, 4, 5, 6, 7, 8], "aspect": [1, 2, 3, 4, 5, 6, 7, 8],
+             "rational6": [1, 2, 3, 4, 5, 11]}[flags_name]
+    sel = [kcols.index(f) for f in free]
+    assert np.allclose(S[np.ix_(sel, sel)], Sref, rtol=1e-8, atol=1e-9 * np.abs(Sref).max())
+    assert np.allclose(b[sel], bref, rtol=1e-8, atol=1e-9 * np.abs(bref).max())
+
+
+def test_config1_mono_chessboard_20_views(pkg, orc, synth):
+    """BASELINE config 1: 9x6 board, 20 views, flags 0 -- full call incl. initialisation."""
+    obj = synth.chessboard(9, 6, 25.0)
+    ms = synth.make_views(obj, 20, 0xC0FFEE + 1)
+    crit = (3, 30, 1e-9)
+    got = pkg.calibrate_camera(obj, ms.img, (640, 480), criteria=crit)
+    ref = orc.calibrate_camera(obj, ms.img, (640, 480), criteria=crit, schur=False)  # dense, OpenCV-shaped
+    _close_params(got, ref)
+    assert abs(got["iters"] - ref["iters"]) <= 1
+    # default criteria (30, DBL_EPSILON): the stop lands on round-off, results must still agree
+    got = pkg.calibrate_camera(obj, ms.img, (640, 480))
+    ref = orc.calibrate_camera(obj, ms.img, (640, 480), schur=False)
+    _close_params(got, ref)
+    # the identity the reference prints (monocular_circle.cpp:96-103)
+    rms2, per_view = pkg.reprojection_error(obj, ms.img, got["K"], got["dist"], got["rvecs"], got["tvecs"])
+    assert abs(rms2 - got["rms"]) < 1e-5 * got["rms"]   # projectPoints rounds to float32
+
+
+def test_reference_mono_chessboard_flags(pkg, orc, synth):
+    """monocular_chessboard.cpp:226-227,315-317: 8x5 board at 20 mm, FIX_ASPECT_RATIO | USE_LU."""
+    obj = synth.chessboard(8, 5, 20.0)
+    ms = synth.make_views(obj, 25, 31, depth=(300.0, 900.0))
+    flags = pkg.CALIB_FIX_ASPECT_RATIO | pkg.CALIB_USE_LU
+    crit = (3, 30, 1e-9)
+    got = pkg.calibrate_camera(obj, ms.img, (640, 480), flags=flags, criteria=crit)
+    ref = orc.calibrate_camera(obj, ms.img, (640, 480), flags=flags, criteria=crit, schur=False)
+    _close_params(got, ref)
+    assert abs(got["iters"] - ref["iters"]) <= 1
+    assert got["K"][0, 0] == got["K"][1, 1]
+
+
+def test_config2_circle_grid_1k_views(pkg, orc, synth):
+    """BASELINE config 2: asymmetric circle grid, 88 points, 1000 noisy views, dist zeros(8,1)-style call."""
+    obj = synth.asymmetric_circles(8, 11, 12.5)
+    ms = synth.make_views(obj, 1000, 0xC0FFEE + 2)
+    crit = (3, 30, 1e-9)
+    got = pkg.calibrate_camera(obj, ms.img, (640, 480), criteria=crit)
+    ref = orc.calibrate_camera(obj, ms.img, (640, 480), criteria=crit, schur=True, nthreads=8)
+    _close_params(got, ref)
+    assert abs(got["iters"] - ref["iters"]) <= 1
+
+
+def test_ragged_views_and_distinct_boards(pkg, orc, synth):
+    rng = np.random.default_rng(5)
+    base = synth.chessboard(9, 6, 25.0)
+    ms = synth.make_views(base, 40, 17)
+    objs, imgs = [], []
+    for i in range(40):
+        keep = np.sort(rng.choice(54, size=int(rng.integers(12, 55)), replace=False))
+        objs.append(base[keep])
+        imgs.append(ms.img[i][keep])
+    crit = (3, 30, 1e-9)
+    got = pkg.calibrate_camera(objs, imgs, (640, 480), criteria=crit)
+    ref = orc.calibrate_camera(objs, imgs, (640, 480), criteria=crit, schur=False)
+    _close_params(got, ref)
+    assert abs(got["iters"] - ref["iters"]) <= 1
+
+
+def test_intrinsic_guess_and_fixed_subsets(pkg, orc, synth):
+    obj = synth.chessboard(9, 6, 25.0)
+    ms = synth.make_views(obj, 30, 23)
+    K0 = np.array([[780.0, 0, 322.0], [0, 790.0, 238.0], [0, 0, 1]])
+    crit = (3, 40, 1e-9)
+    for flags, nd in ((pkg.CALIB_USE_INTRINSIC_GUESS | pkg.CALIB_FIX_PRINCIPAL_POINT | pkg.CALIB_FIX_K3, 5),
+                      (pkg.CALIB_USE_INTRINSIC_GUESS | pkg.CALIB_ZERO_TANGENT_DIST, 4),
+                      (pkg.CALIB_USE_INTRINSIC_GUESS | pkg.CALIB_RATIONAL_MODEL, 8)):
+        got = pkg.calibrate_camera(obj, ms.img, (640, 480), K=K0, dist=np.zeros(nd), ndist=nd, flags=flags, criteria=crit)
+        ref = orc.calibrate_camera(obj, ms.img, (640, 480), K=K0, dist=np.zeros(nd), ndist=nd, flags=flags,
+                                   criteria=crit, schur=False)
+        tol = 1e-6 if nd < 8 else 1e-5   # the 8-coefficient model is nearly degenerate on this data
+        assert abs(got["rms"] - ref["rms"]) <= 1e-6 * ref["rms"]
+        assert np.allclose(got["K"], ref["K"], rtol=tol)
+        assert np.abs(got["rvecs"] - ref["rvecs"]).max() < 10 * tol
+
+
+def test_config3_stereo_reference_flags(pkg, orc, synth):
+    """BASELINE config 3 at reduced N: the flag set of binocular_chessboard.cpp:156-161, criteria (100, 1e-5)."""
+    obj = synth.chessboard(9, 6, 25.0)
+    st = synth.make_stereo(obj, 200, 0xC0FFEE + 3)
+    K1 = pkg.init_camera_matrix_2d(obj, st.img1, (640, 480))
+    K2 = pkg.init_camera_matrix_2d(obj, st.img2, (640, 480))
+    flags = (pkg.CALIB_FIX_ASPECT_RATIO | pkg.CALIB_ZERO_TANGENT_DIST | pkg.CALIB_USE_INTRINSIC_GUESS |
+             pkg.CALIB_SAME_FOCAL_LENGTH | pkg.CALIB_RATIONAL_MODEL | pkg.CALIB_FIX_K3 | pkg.CALIB_FIX_K4 |
+             pkg.CALIB_FIX_K5)
+    crit = (3, 100, 1e-5)
+    got = pkg.stereo_calibrate(obj, st.img1, st.img2, K1, None, K2, None, (640, 480), flags, criteria=crit)
+    ref = orc.stereo_calibrate(obj, st.img1, st.img2, K1, None, K2, None, (640, 480), flags, criteria=crit, schur=True)
+    assert abs(got["rms"] - ref["rms"]) <= REL * ref["rms"]
+    assert abs(got["iters"] - ref["iters"]) <= 1
+    for key in ("K1", "K2", "R", "T", "E", "F"):
+        assert np.allclose(got[key], ref[key], rtol=REL, atol=1e-8 * np.abs(ref[key]).max()), key
+    assert np.allclose(got["d1"], ref["d1"], rtol=REL, atol=1e-9)
+    assert np.allclose(got["d2"], ref["d2"], rtol=REL, atol=1e-9)
+    assert np.abs(got["rt"] - ref["rt"])[:, :3].max() < 1e-6
+
+
+def test_stereo_full_distortion_small_dense(pkg, orc, synth):
+    """The all-free model (config 5's flag set) at a size the dense OpenCV-shaped oracle can solve."""
+    obj = synth.chessboard(9, 6, 25.0)
+    st = synth.make_stereo(obj, 24, 77)
+    K1 = pkg.init_camera_matrix_2d(obj, st.img1, (640, 480))
+    K2 = pkg.init_camera_matrix_2d(obj, st.img2, (640, 480))
+    crit = (3, 100, 1e-7)
+    got = pkg.stereo_calibrate(obj, st.img1, st.img2, K1, None, K2, None, (640, 480), pkg.CALIB_USE_INTRINSIC_GUESS,
+                               criteria=crit)
+    ref = orc.stereo_calibrate(obj, st.img1, st.img2, K1, None, K2, None, (640, 480), orc.USE_INTRINSIC_GUESS,
+                               criteria=crit, schur=False)
+    assert abs(got["rms"] - ref["rms"]) <= REL * ref["rms"]
+    assert abs(got["iters"] - ref["iters"]) <= 1
+    for key in ("K1", "K2", "R", "T", "E", "F"):
+        assert np.allclose(got[key], ref[key], rtol=REL, atol=1e-8 * np.abs(ref[key]).max()), key
+    assert np.allclose(got["d1"][:5], ref["d1"][:5], rtol=1e-5, atol=1e-8)
+
+
+def test_reprojection_error_matches_oracle(pkg, orc, synth):
+    obj = synth.chessboard(9, 6, 25.0)
+    ms = synth.make_views(obj, 50, 3)
+    cam = ms.cam
+    rms, pv, proj = pkg.reprojection_error(obj, ms.img, cam.K(), cam.dist(5), ms.rvec, ms.tvec, want_points=True)
+    want = synth.project(obj, ms.rvec, ms.tvec, cam).reshape(-1, 2)
+    assert np.abs(proj - want).max() < 1e-4            # float32 output
+    rms_ref, pv_ref = orc.reprojection_error(obj, ms.img, cam.K(), cam.dist(5), ms.rvec, ms.tvec)
+    assert abs(rms - rms_ref) < 1e-4 * rms_ref
+    assert np.allclose(pv, pv_ref, rtol=1e-3)
+
+
+def test_full_size_100k_views_properties(pkg, synth):
+    """BASELINE config 4 on one GPU, checked through size-independent properties."""
+    obj = synth.chessboard(9, 6, 25.0)
+    N = 100_000
+    ms = synth.make_views(obj, N, 0xC0FFEE + 4)
+    intr, mask, aspect, rt = _start(pkg, synth, ms)
+    runs = []
+    for _ in range(2):
+        s = pkg.Solver(obj, ms.img)
+        s.set_start(intr, mask, rt)
+        st = s.run(criteria=(3, 30, 1e-10))
+        out = s.get()
+        runs.append((st, out))
+        e2 = s.eval_error()
+        assert abs(e2 - out["err"]) <= 1e-12 * out["err"]       # returned error == error re-evaluated
+        s.close()
+    (st, out), (st_b, out_b) = runs
+    # fixed-order reductions: two runs are bitwise identical
+    assert np.array_equal(out["intr"], out_b["intr"]) and np.array_equal(out["rt"], out_b["rt"])
+    assert st["iters"] == st_b["iters"]
+    rms = np.sqrt(out["err"] / (N * 54))
+    assert 0.40 < rms < 0.44                                    # 0.3 px noise per coordinate
+    cam = ms.cam
+    assert np.allclose(out["intr"][0, :4], [cam.fx, cam.fy, cam.cx, cam.cy], rtol=2e-4)
+    assert np.allclose(out["intr"][0, 4:9], cam.dist(5), atol=1e-2)   # k2, k3 are weakly determined
+    # the RMS recomputed by re-projection agrees (monocular_circle.cpp:5-29)
+    K = np.array([[out["intr"][0, 0], 0, out["intr"][0, 2]], [0, out["intr"][0, 1], out["intr"][0, 3]], [0, 0, 1]])
+    rms2, _ = pkg.reprojection_error(obj, ms.img, K, out["intr"][0, 4:9], out["rt"][:, :3], out["rt"][:, 3:])
+    assert abs(rms2 - rms) < 1e-5 * rms
+
+
+def test_noise_free_recovery_10k_views(pkg, synth):
+    obj = synth.chessboard(9, 6, 25.0)
+    ms = synth.make_views(obj, 10_000, 4242, noise=0.0)
+    intr, mask, aspect, rt = _start(pkg, synth, ms)
+    s = pkg.Solver(obj, ms.img)
+    s.set_start(intr, mask, rt)
+    s.run(criteria=(3, 50, 1e-12))
+    out = s.get()
+    s.close()
+    cam = ms.cam
+    assert np.sqrt(out["err"] / (10_000 * 54)) < 5e-5           # float32 rounding of the image points
+    assert np.allclose(out["intr"][0, :4], [cam.fx, cam.fy, cam.cx, cam.cy], rtol=1e-6)
+    assert np.abs(out["rt"][:, :3] - ms.rvec).max() < 1e-4
+    assert np.abs(out["rt"][:, 3:] - ms.tvec).max() < 5e-2
+
+
+def test_bad_arguments_raise(pkg, synth):
+    obj = synth.chessboard(9, 6, 25.0)
+    ms = synth.make_views(obj, 4, 1)
+    with pytest.raises(pkg.CcalibError):
+        pkg.calibrate_camera(obj, ms.img, (640, 480), ndist=6)
+    with pytest.raises(pkg.CcalibError):
+        pkg.calibrate_camera(obj, ms.img, (640, 480), flags=pkg.CALIB_TILTED_MODEL, ndist=14)
+    with pytest.raises(pkg.CcalibError):
+        pkg.calibrate_camera(obj[:3], ms.img[:, :3], (640, 480))
+    bent = obj.copy()
+    bent[:, 2] = np.linspace(0, 30, len(obj))
+    with pytest.raises(pkg.CcalibError):   # non-planar rig without an intrinsic guess
+        pkg.calibrate_camera(bent, ms.img, (640, 480))
