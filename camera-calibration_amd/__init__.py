@@ -238,10 +238,11 @@ class Solver:
         capi.check(self._lib.ccalib_solver_reduce(self._h, C.c_double(lam), _p(S), _p(b)))
         return S, b
 
-    def time_jacobian(self, reps=10):
-        ms = C.c_double()
-        capi.check(self._lib.ccalib_solver_time_jacobian(self._h, C.c_int(reps), C.byref(ms)))
-        return ms.value
+    def time_kernels(self, reps=10):
+        """Mean launch duration in ms (HIP events): dict(jac_shared, jac_view, err) for camera 0."""
+        ms = (C.c_double * 3)()
+        capi.check(self._lib.ccalib_solver_time_kernels(self._h, C.c_int(reps), ms))
+        return dict(jac_shared=ms[0], jac_view=ms[1], err=ms[2])
 
 
 def mono_start(cam_or_K, dist5=None, flags=0):

@@ -20,7 +20,7 @@ SYMBOLS = [
     "ccalib_rccl_unique_id", "ccalib_solver_use_rccl", "ccalib_solver_use_callback",
     "ccalib_solver_run", "ccalib_solver_get", "ccalib_solver_num_shared",
     "ccalib_solver_eval_error", "ccalib_solver_eval_jacobian", "ccalib_solver_fetch_blocks",
-    "ccalib_solver_reduce", "ccalib_solver_time_jacobian", "ccalib_lm_run",
+    "ccalib_solver_reduce", "ccalib_solver_time_kernels", "ccalib_lm_run",
 ]
 
 OK, ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_STATE, ERR_NUMERIC = range(7)

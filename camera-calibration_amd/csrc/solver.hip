@@ -606,33 +606,37 @@ int ccalib_solver_reduce(ccalib_solver* s, double lambda, double* Ssum, double* 
     return be_reduce(s, lambda, fidx.data(), (int)fidx.size(), Ssum, bsum);
 }
 
-int ccalib_solver_time_jacobian(ccalib_solver* s, int reps, double* ms_per_pass) {
-    if (!s || !s->started || reps < 1 || !ms_per_pass) return set_error(CCALIB_ERR_STATE, "time_jacobian: bad state");
+int ccalib_solver_time_kernels(ccalib_solver* s, int reps, double ms[3]) {
+    if (!s || !s->started || reps < 1 || !ms) return set_error(CCALIB_ERR_STATE, "time_kernels: bad state");
     HIP_TRY(hipSetDevice(s->device));
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
-    int rc = ensure_part(s, (size_t)s->grid_pass * 128);
+    const ModelOps* m = s->ops[0];
+    int rc = ensure_part(s, (size_t)s->grid_pass * m->NRED_U);
     if (rc) return rc;
-    if ((rc = stereo_compose(s, true))) return rc;
-    auto pass = [&]() {
-        for (int c = 0; c < s->ncams; c++) {
-            const ModelOps* m = s->ops[c];
-            CamParams cp = cam_params(s->intr[c], s->aspect[c]);
-            PassArgs a = pass_args(s, c, cam_pose(s, c));
-            m->jac_shared(a, cp, s->grid_pass, s->d_part, s->stream);
-            m->jac_view(a, cp, s->grid_pass, s->d_blk[c], s->npad, s->stream);
-        }
-    };
-    pass();  // warm-up
-    HIP_TRY(hipEventRecord(e0, s->stream));
-    for (int i = 0; i < reps; i++) pass();
-    HIP_TRY(hipEventRecord(e1, s->stream));
-    HIP_TRY(hipEventSynchronize(e1));
-    float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    *ms_per_pass = ms / reps;
+    CamParams cp = cam_params(s->intr[0], s->aspect[0]);
+    PassArgs a = pass_args(s, 0, s->d_pose_cur);
+    for (int which = 0; which < 3; which++) {
+        auto launch = [&]() {
+            if (which == 0)
+                m->jac_shared(a, cp, s->grid_pass, s->d_part, s->stream);
+            else if (which == 1)
+                m->jac_view(a, cp, s->grid_pass, s->d_blk[0], s->npad, s->stream);
+            else
+                launch_err(a, cp, s->rational[0], s->grid_pass, s->d_part, s->stream);
+        };
+        launch();  // warm-up
+        HIP_TRY(hipEventRecord(e0, s->stream));
+        for (int i = 0; i < reps; i++) launch();
+        HIP_TRY(hipEventRecord(e1, s->stream));
+        HIP_TRY(hipEventSynchronize(e1));
+        float t = 0;
+        HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+        ms[which] = t / reps;
+    }
     (void)hipEventDestroy(e0), (void)hipEventDestroy(e1);
+    s->have_cached = false;
     return CCALIB_OK;
 }
 

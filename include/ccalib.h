@@ -191,15 +191,17 @@ int ccalib_solver_get(ccalib_solver* s, double* intr, double* rt, double* lr, do
  *   fetch_blocks   copies per-view V (nviews x 36), W (nviews x ns x 6), ge (nviews x 6) to host
  *   reduce         Schur sums for damping lambda: Ssum = sum_i W_i V_i'^-1 W_i^T (ns x ns),
  *                  bsum = sum_i W_i V_i'^-1 ge_i
- *   time_jacobian  runs the Jacobian pass `reps` times back to back and returns the mean
- *                  duration of one pass in ms, measured with HIP events on the solver's stream
+ *   time_kernels   launches each per-point kernel of camera 0 `reps` times back to back and returns
+ *                  the mean duration of one launch in ms, measured with HIP events on the
+ *                  solver's stream: ms[0] shared-block Jacobian kernel, ms[1] per-view-block
+ *                  Jacobian kernel, ms[2] residual kernel
  */
 int ccalib_solver_num_shared(ccalib_solver* s, int* ns);
 int ccalib_solver_eval_error(ccalib_solver* s, double* err);
 int ccalib_solver_eval_jacobian(ccalib_solver* s, double* U, double* gs, double* err);
 int ccalib_solver_fetch_blocks(ccalib_solver* s, double* V, double* W, double* ge);
 int ccalib_solver_reduce(ccalib_solver* s, double lambda, double* Ssum, double* bsum);
-int ccalib_solver_time_jacobian(ccalib_solver* s, int reps, double* ms_per_pass);
+int ccalib_solver_time_kernels(ccalib_solver* s, int reps, double ms[3]);
 
 /*
  * The host LM driver over a caller-supplied backend: the same state machine ccalib_solver_run
