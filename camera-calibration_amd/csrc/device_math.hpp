@@ -117,6 +117,38 @@ __device__ __forceinline__ void rodrigues(const double r[3], double R[9], double
     }
 }
 
+// A pose in the form the per-view-block kernel keeps in registers: unit axis, the three scalars
+// of R = c I + c1 a a^T + s [a]x, the four scalars of cvRodrigues2's Jacobian
+//   dR/dr_i = r_i (-s I + b1 a a^T + b3 [a]x) + b2 (e_i a^T + a e_i^T) + b4 [e_i]x,
+//   b1 = s - 2 c1/theta, b2 = c1/theta, b3 = c - s/theta, b4 = s/theta,
+// and the translation: 13 doubles instead of the 39 of (R, t, dR/dr).
+struct PoseConst {
+    double ax[3];
+    double c, c1, s, b1, b2, b3, b4;
+    double t[3];
+};
+__device__ __forceinline__ PoseConst pose_const(const double ps[6]) {
+    PoseConst q;
+    double rx = ps[0], ry = ps[1], rz = ps[2];
+    q.t[0] = ps[3], q.t[1] = ps[4], q.t[2] = ps[5];
+    double theta = sqrt(rx * rx + ry * ry + rz * rz);
+    if (theta < 2.220446049250313e-16) {  // R = I, dR/dr_i = [e_i]x
+        q.ax[0] = q.ax[1] = q.ax[2] = 0;
+        q.c = 1, q.c1 = 0, q.s = 0, q.b1 = 0, q.b2 = 0, q.b3 = 0, q.b4 = 1;
+        return q;
+    }
+    double s, c;
+    sincos(theta, &s, &c);
+    double it = 1. / theta, c1 = 1. - c;
+    q.ax[0] = rx * it, q.ax[1] = ry * it, q.ax[2] = rz * it;
+    q.c = c, q.c1 = c1, q.s = s;
+    q.b1 = s - 2 * c1 * it;
+    q.b2 = c1 * it;
+    q.b3 = c - s * it;
+    q.b4 = s * it;
+    return q;
+}
+
 // Everything a pass needs from one point.
 template <class M>
 struct PointOut {

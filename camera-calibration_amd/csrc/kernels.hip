@@ -14,7 +14,7 @@
 //                   every point the lane sees, reduced once per workgroup (wave shuffles + LDS);
 //   * k_jac_view    the per-view blocks JeT*Je, JeT*e, JiT*Je accumulated per lane over the
 //                   lane's points, butterfly-reduced over the view's G lanes, stored SoA;
-//                   per-view constants (R, t, dR/dr) are staged in LDS, not held in VGPRs;
+//                   the pose stays in a 13-double axis-angle form so that the accumulators fit;
 //   * k_schur / k_backsub  one lane per view: 6x6 Cholesky elimination of the view block.
 // Reductions are fixed-order trees (no atomics), so results are bitwise reproducible.
 #include "kernels.hpp"
@@ -27,43 +27,91 @@ namespace ccalib {
 
 static constexpr int kBlock = 256;
 static constexpr int kWaves = kBlock / 64;
-static constexpr int kBoardMax = 1024;  // shared-board points staged in LDS (12 KiB as float)
-static constexpr int kVcStride = 39;    // doubles per view of LDS-resident constants (R 9, t 3, dR 27)
+#ifndef CCALIB_VIEW_MINWAVES
+#define CCALIB_VIEW_MINWAVES 1  // wavefronts per SIMD the per-view-block kernel is compiled for
+#endif
 
+// Dynamic LDS of the per-point kernels (floats):
+//   [shared board: 3 * board_np]  [wave 0 stage] [wave 1 stage] [wave 2 stage] [wave 3 stage]
+// A wave stage holds the image points (float2) of the 64/G views the wavefront owns in the current
+// round -- one contiguous run of the caller's view-major array, copied with coalesced loads -- and,
+// when views have their own object points, those too (3 floats per point).
+extern __shared__ float lds_dyn[];
+
+// A view is owned by G consecutive lanes of one wavefront; a wavefront owns 64/G consecutive views
+// per round and strides over rounds.
+template <int G>
 struct Lane {
-    int g;       // index inside the view's lane group
-    int slot0;   // first view slot of this lane
-    int nslot;   // stride in view slots
-    int vl;      // view slot inside the workgroup
+    static constexpr int VPW = 64 / G;  // views per wavefront per round
+    int lane, g;
+    int v0;      // first view of this wavefront in the current round (wave-uniform)
+    int v;       // this lane's view
+    int stride;  // views per round over the whole grid
+    float2* simg;  // this wavefront's stage
+    float* sobj;
+    const float* board;
+    __device__ __forceinline__ Lane(const PassArgs& a) {
+        lane = threadIdx.x & 63;
+        g = lane & (G - 1);
+        int w = threadIdx.x >> 6;
+        v0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kWaves + w) * VPW);
+        v = v0 + lane / G;
+        stride = gridDim.x * kWaves * VPW;
+        int S = VPW * a.maxnp;
+        float* p = lds_dyn + (a.shared_board ? 3 * a.board_np : 0);
+        int per_wave = S * (a.shared_board ? 2 : 5);
+        simg = reinterpret_cast<float2*>(p + w * per_wave);
+        sobj = p + w * per_wave + 2 * S;
+        board = lds_dyn;
+    }
+    __device__ __forceinline__ void next_round() {
+        v0 += stride;
+        v += stride;
+    }
 };
-__device__ __forceinline__ Lane lane_map(int G) {
-    Lane l;
-    int tid = threadIdx.x;
-    l.g = tid & (G - 1);
-    l.vl = tid / G;
-    int per_block = kBlock / G;
-    l.slot0 = blockIdx.x * per_block + l.vl;
-    l.nslot = gridDim.x * per_block;
-    return l;
-}
 
-__device__ __forceinline__ void stage_board(const PassArgs& a, float* board) {
-    if (a.board_in_lds) {
-        for (int i = threadIdx.x; i < 3 * a.board_np; i += kBlock) board[i] = a.obj[i];
+__device__ __forceinline__ void stage_board(const PassArgs& a) {
+    if (a.shared_board) {
+        for (int i = threadIdx.x; i < 3 * a.board_np; i += kBlock) lds_dyn[i] = a.obj[i];
         __syncthreads();
     }
 }
-__device__ __forceinline__ void load_obj(const PassArgs& a, const float* board, int view_first, int p, double& X,
-                                         double& Y, double& Z) {
-    if (a.board_in_lds) {
-        X = board[3 * p], Y = board[3 * p + 1], Z = board[3 * p + 2];
-    } else {
-        const float* q = a.obj + 3 * (size_t)(a.shared_board ? p : view_first + p);
-        X = q[0], Y = q[1], Z = q[2];
+
+// Copies the points of views [v0, v0 + VPW) into the wavefront's stage; returns the global index of
+// the first staged point.  Only lanes of this wavefront touch the stage, so a wave barrier orders it.
+template <int G>
+__device__ __forceinline__ int stage_views(const PassArgs& a, const Lane<G>& l) {
+    int vA = l.v0 < a.nviews ? l.v0 : a.nviews;
+    int vB = l.v0 + Lane<G>::VPW < a.nviews ? l.v0 + Lane<G>::VPW : a.nviews;
+    int base = a.off[vA], n = a.off[vB] - base;
+    __builtin_amdgcn_wave_barrier();  // the previous round's reads are done before the stage is overwritten
+    for (int i = l.lane; i < n; i += 64) l.simg[i] = a.img[base + i];
+    if (!a.shared_board) {
+        const float* src = a.obj + 3 * (size_t)base;
+        for (int i = l.lane; i < 3 * n; i += 64) l.sobj[i] = src[i];
     }
+    __builtin_amdgcn_wave_barrier();
+    return base;
 }
 
-// Sums `n` per-lane values over the workgroup and writes them to out[0..n).  red: kWaves*n doubles.
+// What a lane needs to start on a view.
+struct ViewHead {
+    int first, np;
+    double ps[6];
+};
+__device__ __forceinline__ ViewHead load_head(const PassArgs& a, int v) {
+    ViewHead h;
+    bool live = v < a.nviews;
+    int vv = live ? v : 0;
+    h.first = a.off[vv];
+    h.np = live ? a.off[vv + 1] - h.first : 0;
+    const double* ps = a.pose + 6 * (size_t)vv;
+#pragma unroll
+    for (int k = 0; k < 6; k++) h.ps[k] = ps[k];
+    return h;
+}
+
+// Sums N per-lane values over the workgroup and writes them to out[0..N).  red: kWaves*N doubles.
 template <int N>
 __device__ __forceinline__ void block_reduce_store(double (&acc)[N], double* red, double* out) {
     int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -81,98 +129,97 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[N], double* red
     }
 }
 
+// Walks the points g, g+G, ... of one staged view; body(X, Y, Z, u, v) is called once per point.
+// `local` is the view's first point relative to the stage.
+template <int G, class Body>
+__device__ __forceinline__ void for_points(const PassArgs& a, const Lane<G>& l, int local, int np, Body&& body) {
+    const float* obj = a.shared_board ? l.board : l.sobj + 3 * local;
+    const float2* img = l.simg + local;
+    for (int p = l.g; p < np; p += G) {
+        float2 m = img[p];
+        float X = obj[3 * p], Y = obj[3 * p + 1], Z = obj[3 * p + 2];
+        body((double)X, (double)Y, (double)Z, (double)m.x, (double)m.y);
+    }
+}
+
 // ---- residual pass -------------------------------------------------------------------------
-template <bool RAT>
+template <bool RAT, int G>
 __global__ __launch_bounds__(kBlock) void k_err(PassArgs a, CamParams cp, double* part) {
     using M = Model<0u, false, RAT>;
-    __shared__ float board[3 * kBoardMax];
     __shared__ double red[kWaves];
-    stage_board(a, board);
-    Lane l = lane_map(a.G);
+    stage_board(a);
+    Lane<G> l(a);
     double acc[1] = {0.};
-    for (int v = l.slot0; v < a.nviews; v += l.nslot) {
-        int first = a.off[v], np = a.off[v + 1] - first;
-        const double* ps = a.pose + 6 * (size_t)v;
-        double r[3] = {ps[0], ps[1], ps[2]}, t[3] = {ps[3], ps[4], ps[5]}, R[9];
-        rodrigues<false>(r, R, nullptr);
-        for (int p = l.g; p < np; p += a.G) {
-            double X, Y, Z;
-            load_obj(a, board, first, p, X, Y, Z);
-            float2 m = a.img[first + p];
-            double Xc = R[0] * X + R[1] * Y + R[2] * Z + t[0];
-            double Yc = R[3] * X + R[4] * Y + R[5] * Z + t[1];
-            double Zc = R[6] * X + R[7] * Y + R[8] * Z + t[2];
+    for (; l.v0 < a.nviews; l.next_round()) {
+        ViewHead h = load_head(a, l.v);
+        int base = stage_views(a, l);
+        double R[9];
+        rodrigues<false>(h.ps, R, nullptr);
+        for_points<G>(a, l, h.first - base, h.np, [&](double X, double Y, double Z, double u, double v) {
+            double Xc = R[0] * X + R[1] * Y + R[2] * Z + h.ps[3];
+            double Yc = R[3] * X + R[4] * Y + R[5] * Z + h.ps[4];
+            double Zc = R[6] * X + R[7] * Y + R[8] * Z + h.ps[5];
             PointOut<M> o;
-            point_eval<M, false, false>(Xc, Yc, Zc, (double)m.x, (double)m.y, cp, o);
+            point_eval<M, false, false>(Xc, Yc, Zc, u, v, cp, o);
             acc[0] += o.ex * o.ex + o.ey * o.ey;
-        }
+        });
     }
     block_reduce_store<1>(acc, red, part + blockIdx.x);
 }
 
 // ---- projectPoints + per-view squared error (the reference's RMS re-check, monocular_circle.cpp:5-29) ----
-template <bool RAT>
+template <bool RAT, int G>
 __global__ __launch_bounds__(kBlock) void k_reproj(PassArgs a, CamParams cp, float2* proj, double* view_err) {
     using M = Model<0u, false, RAT>;
-    __shared__ float board[3 * kBoardMax];
-    stage_board(a, board);
-    Lane l = lane_map(a.G);
-    int nround = (a.nviews + l.nslot - 1) / l.nslot;
-    for (int rd = 0; rd < nround; rd++) {
-        int v = l.slot0 + rd * l.nslot;
-        bool live = v < a.nviews;
-        double acc = 0.;
-        if (live) {
-            int first = a.off[v], np = a.off[v + 1] - first;
-            const double* ps = a.pose + 6 * (size_t)v;
-            double r[3] = {ps[0], ps[1], ps[2]}, t[3] = {ps[3], ps[4], ps[5]}, R[9];
-            rodrigues<false>(r, R, nullptr);
-            for (int p = l.g; p < np; p += a.G) {
-                double X, Y, Z;
-                load_obj(a, board, first, p, X, Y, Z);
-                float2 m = a.img[first + p];
-                double Xc = R[0] * X + R[1] * Y + R[2] * Z + t[0];
-                double Yc = R[3] * X + R[4] * Y + R[5] * Z + t[1];
-                double Zc = R[6] * X + R[7] * Y + R[8] * Z + t[2];
-                PointOut<M> o;
-                point_eval<M, false, false>(Xc, Yc, Zc, 0., 0., cp, o);
-                // projectPoints returns Point2f; the reference compares the rounded values
-                float2 pr = make_float2((float)o.ex, (float)o.ey);
-                if (proj) proj[first + p] = pr;
-                double dx = (double)m.x - (double)pr.x, dy = (double)m.y - (double)pr.y;
-                acc += dx * dx + dy * dy;
-            }
-        }
-        for (int msk = 1; msk < a.G; msk <<= 1) acc += __shfl_xor(acc, msk, 64);
-        if (live && l.g == 0) view_err[v] = acc;
+    stage_board(a);
+    Lane<G> l(a);
+    for (; l.v0 < a.nviews; l.next_round()) {
+        bool live = l.v < a.nviews;
+        ViewHead h = load_head(a, l.v);
+        int base = stage_views(a, l);
+        double R[9], acc = 0.;
+        rodrigues<false>(h.ps, R, nullptr);
+        int p = l.g;
+        for_points<G>(a, l, h.first - base, h.np, [&](double X, double Y, double Z, double u, double v) {
+            double Xc = R[0] * X + R[1] * Y + R[2] * Z + h.ps[3];
+            double Yc = R[3] * X + R[4] * Y + R[5] * Z + h.ps[4];
+            double Zc = R[6] * X + R[7] * Y + R[8] * Z + h.ps[5];
+            PointOut<M> o;
+            point_eval<M, false, false>(Xc, Yc, Zc, 0., 0., cp, o);
+            // projectPoints returns Point2f; the reference compares the rounded values
+            float2 pr = make_float2((float)o.ex, (float)o.ey);
+            if (proj) proj[h.first + p] = pr;
+            p += G;
+            double dx = u - (double)pr.x, dy = v - (double)pr.y;
+            acc += dx * dx + dy * dy;
+        });
+#pragma unroll
+        for (int msk = 1; msk < G; msk <<= 1) acc += __shfl_xor(acc, msk, 64);
+        if (live && l.g == 0) view_err[l.v] = acc;
     }
 }
 
 // ---- shared (intrinsic) block ----------------------------------------------------------------
-template <class M>
+template <class M, int G>
 __global__ __launch_bounds__(kBlock) void k_jac_shared(PassArgs a, CamParams cp, double* part) {
     constexpr int NC = M::NC, NU = M::NU, NR = M::NRED_U;
-    __shared__ float board[3 * kBoardMax];
     __shared__ double red[kWaves * NR];
-    stage_board(a, board);
-    Lane l = lane_map(a.G);
+    stage_board(a);
+    Lane<G> l(a);
     double acc[NR];
 #pragma unroll
     for (int k = 0; k < NR; k++) acc[k] = 0.;
-    for (int v = l.slot0; v < a.nviews; v += l.nslot) {
-        int first = a.off[v], np = a.off[v + 1] - first;
-        const double* ps = a.pose + 6 * (size_t)v;
-        double r[3] = {ps[0], ps[1], ps[2]}, t[3] = {ps[3], ps[4], ps[5]}, R[9];
-        rodrigues<false>(r, R, nullptr);
-        for (int p = l.g; p < np; p += a.G) {
-            double X, Y, Z;
-            load_obj(a, board, first, p, X, Y, Z);
-            float2 m = a.img[first + p];
-            double Xc = R[0] * X + R[1] * Y + R[2] * Z + t[0];
-            double Yc = R[3] * X + R[4] * Y + R[5] * Z + t[1];
-            double Zc = R[6] * X + R[7] * Y + R[8] * Z + t[2];
+    for (; l.v0 < a.nviews; l.next_round()) {
+        ViewHead h = load_head(a, l.v);
+        int base = stage_views(a, l);
+        double R[9];
+        rodrigues<false>(h.ps, R, nullptr);
+        for_points<G>(a, l, h.first - base, h.np, [&](double X, double Y, double Z, double u, double v) {
+            double Xc = R[0] * X + R[1] * Y + R[2] * Z + h.ps[3];
+            double Yc = R[3] * X + R[4] * Y + R[5] * Z + h.ps[4];
+            double Zc = R[6] * X + R[7] * Y + R[8] * Z + h.ps[5];
             PointOut<M> o;
-            point_eval<M, true, false>(Xc, Yc, Zc, (double)m.x, (double)m.y, cp, o);
+            point_eval<M, true, false>(Xc, Yc, Zc, u, v, cp, o);
             // upper triangle of Ji^T Ji, skipping the structural zeros of the fx/fy/cx/cy columns
             static_for<0, NC>([&](auto ia) {
                 constexpr int i = decltype(ia)::value;
@@ -214,7 +261,7 @@ __global__ __launch_bounds__(kBlock) void k_jac_shared(PassArgs a, CamParams cp,
                 }
             });
             acc[NU + NC] += o.ex * o.ex + o.ey * o.ey;
-        }
+        });
     }
     block_reduce_store<NR>(acc, red, part + (size_t)blockIdx.x * NR);
 }
@@ -222,60 +269,58 @@ __global__ __launch_bounds__(kBlock) void k_jac_shared(PassArgs a, CamParams cp,
 // ---- per-view blocks ---------------------------------------------------------------------------
 // blk layout (SoA, leading dimension npad): rows 0..20 V upper triangle, 21..26 ge,
 // 27 + 6*i + b  = W[i][b] (intrinsic column i, pose column b).
-template <class M>
-__global__ __launch_bounds__(kBlock) void k_jac_view(PassArgs a, CamParams cp, double* blk, int npad) {
+//
+// The 21 + 6 + 6*NC accumulators fill most of the register file, so the pose is kept in its
+// 13-double axis-angle form (PoseConst) and R X and the three dR/dr_j X are rebuilt per point from
+// a.X and a x X; with T the 2x3 Jacobian of the pixel w.r.t. the camera-frame point,
+//   T (dR/dr_j X) = a_j (T.base) + b2 ((a.X) T_j + X_j (T.a)) + b4 (X x T)_j,
+//   base = -s X + b1 (a.X) a + b3 (a x X).
+template <class M, int G>
+__global__ __launch_bounds__(kBlock, CCALIB_VIEW_MINWAVES) void k_jac_view(PassArgs a, CamParams cp, double* blk, int npad) {
     constexpr int NC = M::NC, NB = M::NBLK;
-    __shared__ float board[3 * kBoardMax];
-    __shared__ double vc[(kBlock / 2) * kVcStride];
-    stage_board(a, board);
-    Lane l = lane_map(a.G);
-    // every lane of the workgroup runs the same number of slot iterations (barriers inside)
-    int nround = (a.nviews + l.nslot - 1) / l.nslot;
-    for (int rd = 0; rd < nround; rd++) {
-        int v = l.slot0 + rd * l.nslot;
-        bool live = v < a.nviews;
-        double* c = vc + l.vl * kVcStride;
-        if (live && l.g == 0) {
-            const double* ps = a.pose + 6 * (size_t)v;
-            double r[3] = {ps[0], ps[1], ps[2]}, R[9], dR[3][9];
-            rodrigues<true>(r, R, dR);
-#pragma unroll
-            for (int k = 0; k < 9; k++) c[k] = R[k];
-            c[9] = ps[3], c[10] = ps[4], c[11] = ps[5];
-#pragma unroll
-            for (int j = 0; j < 3; j++)
-#pragma unroll
-                for (int k = 0; k < 9; k++) c[12 + 9 * j + k] = dR[j][k];
-        }
-        __syncthreads();
+    stage_board(a);
+    Lane<G> l(a);
+    for (; l.v0 < a.nviews; l.next_round()) {  // wave-uniform trip count (cross-lane shuffles inside)
+        bool live = l.v < a.nviews;
+        ViewHead h = load_head(a, l.v);
+        int base = stage_views(a, l);
+        const PoseConst q = pose_const(h.ps);
         double acc[NB];
 #pragma unroll
         for (int k = 0; k < NB; k++) acc[k] = 0.;
-        int first = 0, np = 0;
-        if (live) {
-            first = a.off[v];
-            np = a.off[v + 1] - first;
-        }
-        for (int p = l.g; p < np; p += a.G) {
-            double X, Y, Z;
-            load_obj(a, board, first, p, X, Y, Z);
-            float2 m = a.img[first + p];
-            double Xc = c[0] * X + c[1] * Y + c[2] * Z + c[9];
-            double Yc = c[3] * X + c[4] * Y + c[5] * Z + c[10];
-            double Zc = c[6] * X + c[7] * Y + c[8] * Z + c[11];
+        for_points<G>(a, l, h.first - base, h.np, [&](double X, double Y, double Z, double u, double v) {
+            double d = q.ax[0] * X + q.ax[1] * Y + q.ax[2] * Z;
+            double wx = q.ax[1] * Z - q.ax[2] * Y, wy = q.ax[2] * X - q.ax[0] * Z, wz = q.ax[0] * Y - q.ax[1] * X;
+            double c1d = q.c1 * d;
+            double Xc = q.t[0] + q.c * X + c1d * q.ax[0] + q.s * wx;
+            double Yc = q.t[1] + q.c * Y + c1d * q.ax[1] + q.s * wy;
+            double Zc = q.t[2] + q.c * Z + c1d * q.ax[2] + q.s * wz;
             PointOut<M> o;
-            point_eval<M, true, true>(Xc, Yc, Zc, (double)m.x, (double)m.y, cp, o);
+            point_eval<M, true, true>(Xc, Yc, Zc, u, v, cp, o);
+            double b1d = q.b1 * d, b2d = q.b2 * d;
+            double base0 = b1d * q.ax[0] + q.b3 * wx - q.s * X;
+            double base1 = b1d * q.ax[1] + q.b3 * wy - q.s * Y;
+            double base2 = b1d * q.ax[2] + q.b3 * wz - q.s * Z;
             double jex[6], jey[6];
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                const double* d = c + 12 + 9 * j;
-                double dX = d[0] * X + d[1] * Y + d[2] * Z;
-                double dY = d[3] * X + d[4] * Y + d[5] * Z;
-                double dZ = d[6] * X + d[7] * Y + d[8] * Z;
-                jex[j] = o.Tx[0] * dX + o.Tx[1] * dY + o.Tx[2] * dZ;
-                jey[j] = o.Ty[0] * dX + o.Ty[1] * dY + o.Ty[2] * dZ;
-                jex[3 + j] = o.Tx[j];
-                jey[3 + j] = o.Ty[j];
+            {
+                const double* T = o.Tx;
+                double A = T[0] * base0 + T[1] * base1 + T[2] * base2;
+                double B = q.b2 * (T[0] * q.ax[0] + T[1] * q.ax[1] + T[2] * q.ax[2]);
+                double C0 = Y * T[2] - Z * T[1], C1 = Z * T[0] - X * T[2], C2 = X * T[1] - Y * T[0];
+                jex[0] = q.ax[0] * A + b2d * T[0] + B * X + q.b4 * C0;
+                jex[1] = q.ax[1] * A + b2d * T[1] + B * Y + q.b4 * C1;
+                jex[2] = q.ax[2] * A + b2d * T[2] + B * Z + q.b4 * C2;
+                jex[3] = T[0], jex[4] = T[1], jex[5] = T[2];
+            }
+            {
+                const double* T = o.Ty;
+                double A = T[0] * base0 + T[1] * base1 + T[2] * base2;
+                double B = q.b2 * (T[0] * q.ax[0] + T[1] * q.ax[1] + T[2] * q.ax[2]);
+                double C0 = Y * T[2] - Z * T[1], C1 = Z * T[0] - X * T[2], C2 = X * T[1] - Y * T[0];
+                jey[0] = q.ax[0] * A + b2d * T[0] + B * X + q.b4 * C0;
+                jey[1] = q.ax[1] * A + b2d * T[1] + B * Y + q.b4 * C1;
+                jey[2] = q.ax[2] * A + b2d * T[2] + B * Z + q.b4 * C2;
+                jey[3] = T[0], jey[4] = T[1], jey[5] = T[2];
             }
 #pragma unroll
             for (int i = 0; i < 6; i++) {
@@ -301,17 +346,17 @@ __global__ __launch_bounds__(kBlock) void k_jac_view(PassArgs a, CamParams cp, d
                     }
                 }
             });
-        }
+        });
         // butterfly over the view's G lanes
-        for (int m = 1; m < a.G; m <<= 1) {
+#pragma unroll
+        for (int m = 1; m < G; m <<= 1) {
 #pragma unroll
             for (int k = 0; k < NB; k++) acc[k] += __shfl_xor(acc[k], m, 64);
         }
         if (live && l.g == 0) {
 #pragma unroll
-            for (int k = 0; k < NB; k++) blk[(size_t)k * npad + v] = acc[k];
+            for (int k = 0; k < NB; k++) blk[(size_t)k * npad + l.v] = acc[k];
         }
-        __syncthreads();
     }
 }
 
@@ -416,13 +461,34 @@ __global__ __launch_bounds__(kBlock) void k_colsum(const double* part, int nrows
 
 // ---- launchers -------------------------------------------------------------------------------
 
+// lanes per view are a compile-time constant of the per-point kernels
+template <class F>
+static void dispatch_G(int G, F&& f) {
+    switch (G) {
+        case 2: f(std::integral_constant<int, 2>{}); break;
+        case 4: f(std::integral_constant<int, 4>{}); break;
+        case 8: f(std::integral_constant<int, 8>{}); break;
+#ifndef CCALIB_FAST_BUILD  // development builds keep compile time down
+        case 16: f(std::integral_constant<int, 16>{}); break;
+        case 32: f(std::integral_constant<int, 32>{}); break;
+        default: f(std::integral_constant<int, 64>{}); break;
+#else
+        default: break;
+#endif
+    }
+}
+
 template <class M>
 static void launch_jac_shared(const PassArgs& a, const CamParams& cp, int grid, double* part, hipStream_t st) {
-    hipLaunchKernelGGL(k_jac_shared<M>, dim3(grid), dim3(kBlock), 0, st, a, cp, part);
+    dispatch_G(a.G, [&](auto g) {
+        k_jac_shared<M, decltype(g)::value><<<dim3(grid), dim3(kBlock), a.lds_bytes, st>>>(a, cp, part);
+    });
 }
 template <class M>
 static void launch_jac_view(const PassArgs& a, const CamParams& cp, int grid, double* blk, int npad, hipStream_t st) {
-    hipLaunchKernelGGL(k_jac_view<M>, dim3(grid), dim3(kBlock), 0, st, a, cp, blk, npad);
+    dispatch_G(a.G, [&](auto g) {
+        k_jac_view<M, decltype(g)::value><<<dim3(grid), dim3(kBlock), a.lds_bytes, st>>>(a, cp, blk, npad);
+    });
 }
 template <int NC>
 static void launch_schur(const double* blk, int npad, int nviews, double lambda, double* part, hipStream_t st) {
@@ -448,10 +514,12 @@ static void launch_backsub(const double* blk, int npad, int nviews, double lambd
 // host driver simply ignores the columns it does not optimise).
 static const ModelOps g_models[] = {
     CCALIB_MODEL_ENTRY(0x1FFu, false, false),  // fx fy cx cy k1 k2 p1 p2 k3   (flags = 0)
+#ifndef CCALIB_FAST_BUILD
     CCALIB_MODEL_ENTRY(0x1FEu, true, false),   // fy cx cy k1 k2 p1 p2 k3, fx tied (FIX_ASPECT_RATIO)
     CCALIB_MODEL_ENTRY(0x83Eu, true, true),    // fy cx cy k1 k2 k6, fx tied (the reference's stereo flags)
     CCALIB_MODEL_ENTRY(0xFFFu, false, true),   // all twelve
     CCALIB_MODEL_ENTRY(0xFFEu, true, true),    // all but fx, fx tied
+#endif
 };
 
 const ModelOps* find_model(unsigned need_mask, bool aspect, bool need_rational) {
@@ -466,18 +534,24 @@ const ModelOps* find_model(unsigned need_mask, bool aspect, bool need_rational) 
 }
 
 void launch_err(const PassArgs& a, const CamParams& cp, bool rational, int grid, double* part, hipStream_t st) {
-    if (rational)
-        hipLaunchKernelGGL(k_err<true>, dim3(grid), dim3(kBlock), 0, st, a, cp, part);
-    else
-        hipLaunchKernelGGL(k_err<false>, dim3(grid), dim3(kBlock), 0, st, a, cp, part);
+    dispatch_G(a.G, [&](auto g) {
+        constexpr int GG = decltype(g)::value;
+        if (rational)
+            k_err<true, GG><<<dim3(grid), dim3(kBlock), a.lds_bytes, st>>>(a, cp, part);
+        else
+            k_err<false, GG><<<dim3(grid), dim3(kBlock), a.lds_bytes, st>>>(a, cp, part);
+    });
 }
 
 void launch_reproj(const PassArgs& a, const CamParams& cp, bool rational, int grid, float2* proj, double* view_err,
                    hipStream_t st) {
-    if (rational)
-        hipLaunchKernelGGL(k_reproj<true>, dim3(grid), dim3(kBlock), 0, st, a, cp, proj, view_err);
-    else
-        hipLaunchKernelGGL(k_reproj<false>, dim3(grid), dim3(kBlock), 0, st, a, cp, proj, view_err);
+    dispatch_G(a.G, [&](auto g) {
+        constexpr int GG = decltype(g)::value;
+        if (rational)
+            k_reproj<true, GG><<<dim3(grid), dim3(kBlock), a.lds_bytes, st>>>(a, cp, proj, view_err);
+        else
+            k_reproj<false, GG><<<dim3(grid), dim3(kBlock), a.lds_bytes, st>>>(a, cp, proj, view_err);
+    });
 }
 
 void launch_colsum(const double* part, int nrows, int n, double* out, hipStream_t st) {
@@ -485,6 +559,10 @@ void launch_colsum(const double* part, int nrows, int n, double* out, hipStream_
 }
 
 int pass_block_size() { return kBlock; }
-int board_lds_capacity() { return kBoardMax; }
+
+size_t pass_lds_bytes(int G, int maxnp, bool shared_board, int board_np) {
+    size_t S = (size_t)(64 / G) * maxnp;
+    return sizeof(float) * ((shared_board ? 3 * (size_t)board_np : 0) + kWaves * S * (shared_board ? 2 : 5));
+}
 
 }  // namespace ccalib

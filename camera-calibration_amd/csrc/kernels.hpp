@@ -14,8 +14,9 @@ struct PassArgs {
     int nviews;
     int shared_board;
     int board_np;
-    int board_in_lds;    // shared board small enough for LDS staging
+    int maxnp;           // largest point count of any view
     int G;               // lanes per view (power of two, 2..64)
+    unsigned lds_bytes;  // dynamic LDS per workgroup, from pass_lds_bytes()
 };
 
 struct DeltaC {
@@ -50,6 +51,7 @@ void launch_reproj(const PassArgs&, const CamParams&, bool rational, int grid, f
                    hipStream_t);
 void launch_colsum(const double* part, int nrows, int n, double* out, hipStream_t);
 int pass_block_size();
-int board_lds_capacity();
+// dynamic LDS one workgroup of the per-point kernels needs
+size_t pass_lds_bytes(int G, int maxnp, bool shared_board, int board_np);
 
 }  // namespace ccalib

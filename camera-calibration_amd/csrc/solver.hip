@@ -41,9 +41,12 @@ using namespace ccalib;
 
 struct ccalib_solver {
     int device = 0, ncams = 1, nviews = 0, total = 0, maxnp = 0;
-    bool shared_board = false, board_in_lds = false;
+    bool shared_board = false;
     int board_np = 0;
-    int G = 4, grid_pass = 0, nblk64 = 0, npad = 0;
+    int G = 4, nblk64 = 0, npad = 0;
+    int grid_view = 0;  // per-view kernels: every wavefront does one round
+    int grid_red = 0;   // reducing kernels: fewer workgroups, several rounds each, one reduction at the end
+    unsigned lds_bytes = 0;
     hipStream_t stream = nullptr;
     float* d_obj = nullptr;
     int* d_off = nullptr;
@@ -111,7 +114,8 @@ PassArgs pass_args(const ccalib_solver* s, int cam, const double* pose) {
     a.nviews = s->nviews;
     a.shared_board = s->shared_board;
     a.board_np = s->board_np;
-    a.board_in_lds = s->board_in_lds;
+    a.maxnp = s->maxnp;
+    a.lds_bytes = s->lds_bytes;
     a.G = s->G;
     return a;
 }
@@ -198,10 +202,10 @@ int be_jac(void* user, const double* shared, double lambda_hint, double* U, doub
         const ModelOps* m = s->ops[c];
         CamParams cp = cam_params(s->intr[c], s->aspect[c]);
         PassArgs a = pass_args(s, c, cam_pose(s, c));
-        if ((rc = ensure_part(s, (size_t)s->grid_pass * m->NRED_U))) return rc;
-        m->jac_shared(a, cp, s->grid_pass, s->d_part, s->stream);
-        launch_colsum(s->d_part, s->grid_pass, m->NRED_U, s->d_red + ofs, s->stream);
-        m->jac_view(a, cp, s->grid_pass, s->d_blk[c], s->npad, s->stream);
+        if ((rc = ensure_part(s, (size_t)s->grid_red * m->NRED_U))) return rc;
+        m->jac_shared(a, cp, s->grid_red, s->d_part, s->stream);
+        launch_colsum(s->d_part, s->grid_red, m->NRED_U, s->d_red + ofs, s->stream);
+        m->jac_view(a, cp, s->grid_view, s->d_blk[c], s->npad, s->stream);
         cam_ofs[c] = ofs;
         ofs += m->NRED_U;
     }
@@ -285,7 +289,7 @@ int be_step_err(void* user, double lambda, const int* fidx, int nf, const double
     int rc;
     std::vector<double> dfull(s->ns(), 0.);
     for (int a = 0; a < nf; a++) dfull[fidx[a]] = dshared[a];
-    if ((rc = ensure_part(s, (size_t)std::max(s->nblk64 * 2, s->grid_pass)))) return rc;
+    if ((rc = ensure_part(s, (size_t)std::max(s->nblk64 * 2, s->grid_red)))) return rc;
     if (s->ncams == 1) {
         DeltaC dc;
         for (int k = 0; k < I_NMODEL; k++) dc.v[k] = 0;
@@ -307,8 +311,8 @@ int be_step_err(void* user, double lambda, const int* fidx, int nf, const double
     for (int c = 0; c < s->ncams; c++) {
         CamParams cp = cam_params(s->intr[c], s->aspect[c]);
         PassArgs a = pass_args(s, c, cam_pose(s, c));
-        launch_err(a, cp, s->rational[c], s->grid_pass, s->d_part, s->stream);
-        launch_colsum(s->d_part, s->grid_pass, 1, s->d_red + 2 + c, s->stream);
+        launch_err(a, cp, s->rational[c], s->grid_red, s->d_part, s->stream);
+        launch_colsum(s->d_part, s->grid_red, 1, s->d_red + 2 + c, s->stream);
     }
     if ((rc = finish_reduction(s, 2 + s->ncams))) return rc;
     *dnorm2 = s->h_red[0];
@@ -348,20 +352,22 @@ void be_fixup(void* user, double* shared, double* prev) {
         }
 }
 
-int choose_G(int nviews, int maxnp) {
-    if (const char* e = std::getenv("CCALIB_G")) {
-        int g = std::atoi(e);
-        if (g >= 2 && g <= 64 && (g & (g - 1)) == 0) return g;
-    }
-    // enough wavefronts to fill 256 CUs several times over, then the best lane utilisation
-    int g0 = 2;
-    while (g0 < 64 && (long long)nviews * g0 / 64 < 8192) g0 <<= 1;
-    while (g0 > 2 && g0 > maxnp) g0 >>= 1;
-    int best = g0;
-    double best_u = 0;
-    for (int g = g0; g >= 2 && g >= g0 / 2; g >>= 1) {
-        double u = (double)maxnp / (g * ((maxnp + g - 1) / g));
-        if (u > best_u + 1e-9) best_u = u, best = g;
+// Lanes per view.  Fewer lanes per view mean more points per lane, which amortises the per-view
+// work (pose set-up, cross-lane reduction, block stores); more lanes per view mean more wavefronts.
+// Pick the smallest G that still gives every SIMD a few wavefronts, within the LDS budget.
+int choose_G(int nviews, int maxnp, bool shared, int board_np) {
+    const size_t lds_cap = 64 * 1024;
+    int g_env = 0;
+    if (const char* e = std::getenv("CCALIB_G")) g_env = std::atoi(e);
+    if (g_env >= 2 && g_env <= 64 && (g_env & (g_env - 1)) == 0 &&
+        pass_lds_bytes(g_env, maxnp, shared, board_np) <= lds_cap)
+        return g_env;
+    int best = 0;
+    for (int g = 2; g <= 64; g <<= 1) {
+        if (pass_lds_bytes(g, maxnp, shared, board_np) > lds_cap) continue;
+        best = g;
+        long long waves = ((long long)nviews * g + 63) / 64;
+        if (waves >= 2048 || g >= maxnp) break;  // 2 wavefronts on each of the 1024 SIMDs
     }
     return best;
 }
@@ -395,12 +401,27 @@ int ccalib_solver_create(ccalib_solver** out, int device, int ncams, int nviews,
         s->maxnp = std::max(s->maxnp, npts[i]);
     }
     s->total = off[nviews];
+    // a shared board too large for LDS is replicated per view instead
+    std::vector<float> expanded;
+    if (shared_board && npts[0] > 1024) {
+        expanded.resize((size_t)3 * s->total);
+        for (int i = 0; i < nviews; i++) std::memcpy(&expanded[(size_t)3 * off[i]], obj_xyz, sizeof(float) * 3 * npts[0]);
+        obj_xyz = expanded.data();
+        shared_board = 0;
+        s->shared_board = false;
+    }
     s->board_np = shared_board ? npts[0] : 0;
-    s->board_in_lds = shared_board && s->board_np <= board_lds_capacity();
-    s->G = choose_G(nviews, s->maxnp);
-    int per_block = pass_block_size() / s->G;
-    s->grid_pass = (nviews + per_block - 1) / per_block;
-    if (const char* e = std::getenv("CCALIB_GRID")) s->grid_pass = std::max(1, std::min(s->grid_pass, std::atoi(e)));
+    s->G = choose_G(nviews, s->maxnp, s->shared_board, s->board_np);
+    if (!s->G) {
+        int mp = s->maxnp;
+        delete s;
+        return set_error(CCALIB_ERR_UNSUPPORTED, "a view with %d points does not fit the kernels' LDS staging", mp);
+    }
+    s->lds_bytes = (unsigned)pass_lds_bytes(s->G, s->maxnp, s->shared_board, s->board_np);
+    int views_per_block = pass_block_size() / s->G;
+    s->grid_view = (nviews + views_per_block - 1) / views_per_block;
+    s->grid_red = std::min(s->grid_view, 512);
+    if (const char* e = std::getenv("CCALIB_GRID_RED")) s->grid_red = std::max(1, std::min(s->grid_view, std::atoi(e)));
     s->nblk64 = (nviews + 63) / 64;
     s->npad = (nviews + 63) / 64 * 64;
     HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
@@ -550,14 +571,14 @@ int ccalib_solver_eval_error(ccalib_solver* s, double* err) {
     if (!s || !s->started || !err) return set_error(CCALIB_ERR_STATE, "eval_error before set_start");
     HIP_TRY(hipSetDevice(s->device));
     int rc;
-    if ((rc = ensure_part(s, s->grid_pass))) return rc;
+    if ((rc = ensure_part(s, s->grid_red))) return rc;
     if ((rc = stereo_compose(s, false))) return rc;
     for (int c = 0; c < s->ncams; c++) {
         CamParams cp = cam_params(s->intr[c], s->aspect[c]);
         if (s->aspect[c] != 0) cp.fx = cp.fy * s->aspect[c];
         PassArgs a = pass_args(s, c, cam_pose(s, c));
-        launch_err(a, cp, s->rational[c], s->grid_pass, s->d_part, s->stream);
-        launch_colsum(s->d_part, s->grid_pass, 1, s->d_red + c, s->stream);
+        launch_err(a, cp, s->rational[c], s->grid_red, s->d_part, s->stream);
+        launch_colsum(s->d_part, s->grid_red, 1, s->d_red + c, s->stream);
     }
     if ((rc = finish_reduction(s, s->ncams))) return rc;
     *err = s->h_red[0] + (s->ncams == 2 ? s->h_red[1] : 0.);
@@ -613,18 +634,18 @@ int ccalib_solver_time_kernels(ccalib_solver* s, int reps, double ms[3]) {
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     const ModelOps* m = s->ops[0];
-    int rc = ensure_part(s, (size_t)s->grid_pass * m->NRED_U);
+    int rc = ensure_part(s, (size_t)s->grid_red * m->NRED_U);
     if (rc) return rc;
     CamParams cp = cam_params(s->intr[0], s->aspect[0]);
     PassArgs a = pass_args(s, 0, s->d_pose_cur);
     for (int which = 0; which < 3; which++) {
         auto launch = [&]() {
             if (which == 0)
-                m->jac_shared(a, cp, s->grid_pass, s->d_part, s->stream);
+                m->jac_shared(a, cp, s->grid_red, s->d_part, s->stream);
             else if (which == 1)
-                m->jac_view(a, cp, s->grid_pass, s->d_blk[0], s->npad, s->stream);
+                m->jac_view(a, cp, s->grid_view, s->d_blk[0], s->npad, s->stream);
             else
-                launch_err(a, cp, s->rational[0], s->grid_pass, s->d_part, s->stream);
+                launch_err(a, cp, s->rational[0], s->grid_red, s->d_part, s->stream);
         };
         launch();  // warm-up
         HIP_TRY(hipEventRecord(e0, s->stream));
@@ -671,7 +692,7 @@ int ccalib_reprojection_error(int nviews, const int* npts, const float* obj_xyz,
     bool rational = intr[9] != 0. || intr[10] != 0. || intr[11] != 0.;
     if (proj_uv) HIP_TRY(hipMalloc(&g.proj, sizeof(float2) * s->total));
     HIP_TRY(hipMalloc(&g.verr, sizeof(double) * nviews));
-    launch_reproj(pass_args(s, 0, s->d_pose_cur), cp, rational, s->grid_pass, g.proj, g.verr, s->stream);
+    launch_reproj(pass_args(s, 0, s->d_pose_cur), cp, rational, s->grid_view, g.proj, g.verr, s->stream);
     std::vector<double> verr(nviews);
     HIP_TRY(hipMemcpyAsync(verr.data(), g.verr, sizeof(double) * nviews, hipMemcpyDeviceToHost, s->stream));
     if (proj_uv) HIP_TRY(hipMemcpyAsync(proj_uv, g.proj, sizeof(float2) * s->total, hipMemcpyDeviceToHost, s->stream));
