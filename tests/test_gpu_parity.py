@@ -264,3 +264,43 @@ def test_bad_arguments_raise(pkg, synth):
     bent[:, 2] = np.linspace(0, 30, len(obj))
     with pytest.raises(pkg.CcalibError):   # non-planar rig without an intrinsic guess
         pkg.calibrate_camera(bent, ms.img, (640, 480))
+
+
+def _run_shard_worker(mode, port):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                           "--master-addr", "127.0.0.1", "--master-port", str(port),
+                           os.path.join(root, "tests", "gpu_shard_worker.py"), mode],
+                          env=env, capture_output=True, text=True, timeout=280)
+
+
+def test_two_ranks_shard_views_callback_allreduce():
+    """N > 1 through the real kernels: two processes (sharing the box's one GPU) own half the views each."""
+    out = _run_shard_worker("callback", 29621)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "GPU_SHARDED_OK callback" in out.stdout
+
+
+def test_rccl_allreduce_path(pkg, synth):
+    """In-stream RCCL all-reduce: a one-rank communicator on this box (multi-rank needs one GPU per rank)."""
+    import ctypes as C
+    obj = synth.chessboard(9, 6, 25.0)
+    ms = synth.make_views(obj, 300, 5)
+    intr, mask, aspect, rt = _start(pkg, synth, ms)
+    res = []
+    for use in (False, True):
+        s = pkg.Solver(obj, ms.img)
+        if use:
+            buf = C.create_string_buffer(128)
+            pkg.capi.check(pkg.capi.load().ccalib_rccl_unique_id(buf))
+            s.use_rccl(1, 0, buf.raw)
+        s.set_start(intr, mask, rt)
+        st = s.run(criteria=(3, 30, 1e-10))
+        res.append((st, s.get()))
+        s.close()
+    assert res[0][0]["iters"] == res[1][0]["iters"]
+    assert np.array_equal(res[0][1]["intr"], res[1][1]["intr"])
