@@ -304,3 +304,24 @@ def test_rccl_allreduce_path(pkg, synth):
         s.close()
     assert res[0][0]["iters"] == res[1][0]["iters"]
     assert np.array_equal(res[0][1]["intr"], res[1][1]["intr"])
+
+
+def test_cpp_dropin_header_end_to_end():
+    """The C++ header with OpenCV's call shapes (include/ccalib.hpp), driven like the reference's programs:
+    calibrateCamera -> reprojection RMS -> initCameraMatrix2D -> stereoCalibrate on noise-free synthetic
+    views, so the known cameras must come back."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([os.path.join(root, "tests", "cpp", "dropin_check")], capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    r = {ln.split()[0]: [float(x) for x in ln.split()[1:]] for ln in out.stdout.splitlines() if ln.strip()}
+    assert r["mono_rms"][0] < 2e-4                       # float32 image points: ~1e-5 px quantisation
+    assert np.allclose(r["mono_K"], [812.5, 806.25, 322.0, 238.5], rtol=1e-4)
+    assert np.allclose(r["mono_D"], [-0.21, 0.09, 0.0007, -0.0004, -0.015], atol=2e-3)
+    assert abs(r["reproj_rms"][0] - r["mono_rms"][0]) <= 1e-6 * max(r["mono_rms"][0], 1e-12) + 1e-9
+    assert r["stereo_rms"][0] < 2e-4
+    assert np.allclose(r["stereo_T"], [-120.0, 1.5, 2.5], atol=2e-2)
+    assert np.allclose(r["stereo_K2"], [798.0, 801.5, 316.5, 244.0], rtol=1e-4)
+    assert r["bad_input_throws"][0] == 1

@@ -36,6 +36,19 @@ def test_compute_fails_loudly_without_a_gpu(pkg, synth):
         pkg.Solver(obj, ms.img)
 
 
+def test_cpp_dropin_header_builds_and_reports_missing_gpu():
+    """include/ccalib.hpp (the cv::-shaped C++ surface) links against the C ABI with plain g++; without a
+    GPU the first compute call throws ccalib::Exception carrying CCALIB_ERR_NO_DEVICE."""
+    import torch
+    exe = os.path.join(ROOT, "tests", "cpp", "dropin_check")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 3, out.stdout + out.stderr
+    assert out.stdout.startswith("exception 3 ")
+
+
 def test_host_initialisation_matches_oracle(pkg, orc, synth):
     obj = synth.chessboard(9, 6, 25.0)
     ms = synth.make_views(obj, 12, 9)
