@@ -215,6 +215,47 @@ __device__ __forceinline__ void point_eval(double Xc, double Yc, double Zc, doub
     }
 }
 
+// One point of one view: residual, intrinsic columns (o) and the two rows of the 2x6 pose
+// Jacobian (jex, jey: d u, d v / d (r0 r1 r2 t0 t1 t2)), from the 13-double pose form.  With T the
+// 2x3 Jacobian of the pixel w.r.t. the camera-frame point,
+//   T (dR/dr_j X) = a_j (T.base) + b2 ((a.X) T_j + X_j (T.a)) + b4 (X x T)_j,
+//   base = -s X + b1 (a.X) a + b3 (a x X).
+template <class M>
+__device__ __forceinline__ void point_jacobian(const PoseConst& q, const CamParams& cp, double X, double Y, double Z,
+                                               double u, double v, PointOut<M>& o, double jex[6], double jey[6]) {
+    double d = q.ax[0] * X + q.ax[1] * Y + q.ax[2] * Z;
+    double wx = q.ax[1] * Z - q.ax[2] * Y, wy = q.ax[2] * X - q.ax[0] * Z, wz = q.ax[0] * Y - q.ax[1] * X;
+    double c1d = q.c1 * d;
+    double Xc = q.t[0] + q.c * X + c1d * q.ax[0] + q.s * wx;
+    double Yc = q.t[1] + q.c * Y + c1d * q.ax[1] + q.s * wy;
+    double Zc = q.t[2] + q.c * Z + c1d * q.ax[2] + q.s * wz;
+    point_eval<M, true, true>(Xc, Yc, Zc, u, v, cp, o);
+    double b1d = q.b1 * d, b2d = q.b2 * d;
+    double base0 = b1d * q.ax[0] + q.b3 * wx - q.s * X;
+    double base1 = b1d * q.ax[1] + q.b3 * wy - q.s * Y;
+    double base2 = b1d * q.ax[2] + q.b3 * wz - q.s * Z;
+    {
+        const double* T = o.Tx;
+        double A = T[0] * base0 + T[1] * base1 + T[2] * base2;
+        double B = q.b2 * (T[0] * q.ax[0] + T[1] * q.ax[1] + T[2] * q.ax[2]);
+        double C0 = Y * T[2] - Z * T[1], C1 = Z * T[0] - X * T[2], C2 = X * T[1] - Y * T[0];
+        jex[0] = q.ax[0] * A + b2d * T[0] + B * X + q.b4 * C0;
+        jex[1] = q.ax[1] * A + b2d * T[1] + B * Y + q.b4 * C1;
+        jex[2] = q.ax[2] * A + b2d * T[2] + B * Z + q.b4 * C2;
+        jex[3] = T[0], jex[4] = T[1], jex[5] = T[2];
+    }
+    {
+        const double* T = o.Ty;
+        double A = T[0] * base0 + T[1] * base1 + T[2] * base2;
+        double B = q.b2 * (T[0] * q.ax[0] + T[1] * q.ax[1] + T[2] * q.ax[2]);
+        double C0 = Y * T[2] - Z * T[1], C1 = Z * T[0] - X * T[2], C2 = X * T[1] - Y * T[0];
+        jey[0] = q.ax[0] * A + b2d * T[0] + B * X + q.b4 * C0;
+        jey[1] = q.ax[1] * A + b2d * T[1] + B * Y + q.b4 * C1;
+        jey[2] = q.ax[2] * A + b2d * T[2] + B * Z + q.b4 * C2;
+        jey[3] = T[0], jey[4] = T[1], jey[5] = T[2];
+    }
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);

@@ -21,6 +21,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "device_math.hpp"
 
 namespace ccalib {
@@ -267,14 +270,12 @@ __global__ __launch_bounds__(kBlock) void k_jac_shared(PassArgs a, CamParams cp,
 }
 
 // ---- per-view blocks ---------------------------------------------------------------------------
-// blk layout (SoA, leading dimension npad): rows 0..20 V upper triangle, 21..26 ge,
+// blk quantities (addressed through blk_index): 0..20 V upper triangle, 21..26 ge,
 // 27 + 6*i + b  = W[i][b] (intrinsic column i, pose column b).
 //
 // The 21 + 6 + 6*NC accumulators fill most of the register file, so the pose is kept in its
-// 13-double axis-angle form (PoseConst) and R X and the three dR/dr_j X are rebuilt per point from
-// a.X and a x X; with T the 2x3 Jacobian of the pixel w.r.t. the camera-frame point,
-//   T (dR/dr_j X) = a_j (T.base) + b2 ((a.X) T_j + X_j (T.a)) + b4 (X x T)_j,
-//   base = -s X + b1 (a.X) a + b3 (a x X).
+// 13-double axis-angle form (PoseConst) and R X and the three dR/dr_j X are rebuilt per point
+// (point_jacobian).
 template <class M, int G>
 __global__ __launch_bounds__(kBlock, CCALIB_VIEW_MINWAVES) void k_jac_view(PassArgs a, CamParams cp, double* blk, int npad) {
     constexpr int NC = M::NC, NB = M::NBLK;
@@ -289,39 +290,9 @@ __global__ __launch_bounds__(kBlock, CCALIB_VIEW_MINWAVES) void k_jac_view(PassA
 #pragma unroll
         for (int k = 0; k < NB; k++) acc[k] = 0.;
         for_points<G>(a, l, h.first - base, h.np, [&](double X, double Y, double Z, double u, double v) {
-            double d = q.ax[0] * X + q.ax[1] * Y + q.ax[2] * Z;
-            double wx = q.ax[1] * Z - q.ax[2] * Y, wy = q.ax[2] * X - q.ax[0] * Z, wz = q.ax[0] * Y - q.ax[1] * X;
-            double c1d = q.c1 * d;
-            double Xc = q.t[0] + q.c * X + c1d * q.ax[0] + q.s * wx;
-            double Yc = q.t[1] + q.c * Y + c1d * q.ax[1] + q.s * wy;
-            double Zc = q.t[2] + q.c * Z + c1d * q.ax[2] + q.s * wz;
             PointOut<M> o;
-            point_eval<M, true, true>(Xc, Yc, Zc, u, v, cp, o);
-            double b1d = q.b1 * d, b2d = q.b2 * d;
-            double base0 = b1d * q.ax[0] + q.b3 * wx - q.s * X;
-            double base1 = b1d * q.ax[1] + q.b3 * wy - q.s * Y;
-            double base2 = b1d * q.ax[2] + q.b3 * wz - q.s * Z;
             double jex[6], jey[6];
-            {
-                const double* T = o.Tx;
-                double A = T[0] * base0 + T[1] * base1 + T[2] * base2;
-                double B = q.b2 * (T[0] * q.ax[0] + T[1] * q.ax[1] + T[2] * q.ax[2]);
-                double C0 = Y * T[2] - Z * T[1], C1 = Z * T[0] - X * T[2], C2 = X * T[1] - Y * T[0];
-                jex[0] = q.ax[0] * A + b2d * T[0] + B * X + q.b4 * C0;
-                jex[1] = q.ax[1] * A + b2d * T[1] + B * Y + q.b4 * C1;
-                jex[2] = q.ax[2] * A + b2d * T[2] + B * Z + q.b4 * C2;
-                jex[3] = T[0], jex[4] = T[1], jex[5] = T[2];
-            }
-            {
-                const double* T = o.Ty;
-                double A = T[0] * base0 + T[1] * base1 + T[2] * base2;
-                double B = q.b2 * (T[0] * q.ax[0] + T[1] * q.ax[1] + T[2] * q.ax[2]);
-                double C0 = Y * T[2] - Z * T[1], C1 = Z * T[0] - X * T[2], C2 = X * T[1] - Y * T[0];
-                jey[0] = q.ax[0] * A + b2d * T[0] + B * X + q.b4 * C0;
-                jey[1] = q.ax[1] * A + b2d * T[1] + B * Y + q.b4 * C1;
-                jey[2] = q.ax[2] * A + b2d * T[2] + B * Z + q.b4 * C2;
-                jey[3] = T[0], jey[4] = T[1], jey[5] = T[2];
-            }
+            point_jacobian<M>(q, cp, X, Y, Z, u, v, o, jex, jey);
 #pragma unroll
             for (int i = 0; i < 6; i++) {
 #pragma unroll
@@ -355,9 +326,205 @@ __global__ __launch_bounds__(kBlock, CCALIB_VIEW_MINWAVES) void k_jac_view(PassA
         }
         if (live && l.g == 0) {
 #pragma unroll
-            for (int k = 0; k < NB; k++) blk[(size_t)k * npad + l.v] = acc[k];
+            for (int k = 0; k < NB; k++) blk[blk_index(NB, k, l.v)] = acc[k];
         }
     }
+}
+
+// ---- fused Jacobian pass on the FP64 matrix pipe ---------------------------------------------
+// For column sets with NC + 7 <= 16 the whole normal-equation update of a view is one product:
+// with A = [Ji | Je | e] (2P x 16: intrinsic columns, six pose columns, the residual as a column),
+//   A^T A = [ U    W    gc  ]
+//           [ W^T  V    ge  ]
+//           [ gc^T ge^T err ]
+// which v_mfma_f64_16x16x4_f64 accumulates four rows of A at a time.  One wavefront owns one view
+// at a time: lane p evaluates point p (residual, intrinsic columns, pose columns), writes its two
+// rows of A into a per-wave LDS buffer stored column-major, and the wavefront then streams the
+// buffer through the MFMA (the A and B operands are the same register: the product is symmetric).
+// A workgroup owns one tile of kTileViews = 4 views (one per wavefront) and writes that tile of
+// blk contiguously; the shared block is accumulated over the wavefront's views in registers and
+// written once per wavefront (fixed assignment, so sums are bitwise reproducible).
+//
+// LDS (after the shared board): per wavefront 16 columns x RS doubles, RS >= 2*CH rows with
+// RS mod 32 in {2, 14, 18, 30} so that the 16-byte reads of 16 columns fall in disjoint banks.
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(64) void k_pose_const(const double* pose, int nviews, double* pc) {
+    int v = blockIdx.x * 64 + threadIdx.x;
+    if (v >= nviews) return;
+    double ps[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) ps[k] = pose[6 * (size_t)v + k];
+    PoseConst q = pose_const(ps);
+    double* o = pc + kPoseConstStride * (size_t)v;
+    o[0] = q.ax[0], o[1] = q.ax[1], o[2] = q.ax[2], o[3] = q.c, o[4] = q.c1, o[5] = q.s, o[6] = q.b1, o[7] = q.b2;
+    o[8] = q.b3, o[9] = q.b4, o[10] = q.t[0], o[11] = q.t[1], o[12] = q.t[2], o[13] = 0, o[14] = 0, o[15] = 0;
+}
+
+template <class M, bool SHARED>
+__global__ __launch_bounds__(kBlock, 2) void k_jac_fused(PassArgs a, CamParams cp, const int* __restrict__ off,
+                                                         const double* __restrict__ pc, double* __restrict__ blk,
+                                                         double* __restrict__ part, int RS, int CH, int dbg) {
+    constexpr int NC = M::NC, NB = M::NBLK, NU = M::NU, NR = M::NRED_U;
+    constexpr int CPOSE = NC, CRES = NC + 6, NCOL = NC + 7;
+    static_assert(NCOL <= 16, "column set does not fit one 16x16 tile");
+    static_assert(kWaves == kTileViews, "one wavefront per view of a tile");
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    stage_board(a);
+    const int board_f = SHARED ? (3 * a.board_np + 3) / 4 * 4 : 0;  // floats, 16-byte granules
+    double* const ldsd = reinterpret_cast<double*>(lds_dyn);  // indexed, so every access stays an LDS access
+    const int jt = board_f / 2 + w * 16 * RS;                 // this wavefront's buffer (in doubles)
+    for (int c = NCOL; c < 16; c++)  // columns the set does not use stay zero
+        for (int r = lane; r < RS; r += 64) ldsd[jt + c * RS + r] = 0.;
+    // which results this lane's four accumulator registers hold: D[row][col], col = lane & 15,
+    // row = (lane >> 4) + 4 * reg
+    const int col = lane & 15, rq = lane >> 4;
+    int qv[4], qu[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        int row = rq + 4 * r;
+        int pc_ = col - CPOSE, pr_ = row - CPOSE;
+        qv[r] = -1, qu[r] = -1;
+        if (pc_ >= 0 && pc_ < 6) {
+            if (row < NC)
+                qv[r] = 27 + 6 * row + pc_;
+            else if (pr_ < 6 && pr_ <= pc_)
+                qv[r] = tri6(pr_, pc_);
+            else if (row == CRES)
+                qv[r] = 21 + pc_;
+        }
+        if (row < NC && col < NC && row <= col) qu[r] = row * NC - row * (row - 1) / 2 + (col - row);
+        if (row < NC && col == CRES) qu[r] = NU + row;
+        if (row == CRES && col == CRES) qu[r] = NU + NC;
+    }
+    int voff[4];  // byte offset of each register's result inside a tile of blk
+#pragma unroll
+    for (int r = 0; r < 4; r++) voff[r] = qv[r] >= 0 ? (qv[r] * kTileViews + w) * (int)sizeof(double) : 0x7fffffff;
+    double4_t usum = {0., 0., 0., 0.};
+    const int ntiles = (a.nviews + kTileViews - 1) / kTileViews;
+    // What the wavefront needs to start on a view -- point range, this lane's image point, the pose --
+    // is fetched one view ahead, between the point phase and the matrix phase of the view before,
+    // so that its latency hides under the MFMAs.  The pose record (26 dwords) is fetched with ONE
+    // dword load, lane k taking dword k, and spread to scalar registers with v_readlane when the view
+    // starts: a broadcast vector load of the record would cost 16 L1 cycles per 16 bytes, and scalar
+    // loads share their wait counter with the LDS reads of the matrix phase.
+    int first = 0, np = 0;
+    float2 mpt = make_float2(0.f, 0.f);
+    unsigned qword = 0;
+    auto fetch = [&](int v) {
+        if constexpr (SHARED) {
+            np = a.board_np, first = v * a.board_np;
+        } else {
+            first = off[v], np = off[v + 1] - first;
+        }
+        if (lane < np && !(dbg & 8)) mpt = a.img[first + lane];
+        const unsigned* qs = reinterpret_cast<const unsigned*>(pc + kPoseConstStride * (size_t)v);
+        qword = qs[lane & 31];
+    };
+    // with a shared board lane p always works on board point p
+    float bX = 0.f, bY = 0.f, bZ = 0.f;
+    if constexpr (SHARED) {
+        if (lane < a.board_np) bX = lds_dyn[3 * lane], bY = lds_dyn[3 * lane + 1], bZ = lds_dyn[3 * lane + 2];
+    }
+    int tile = blockIdx.x;
+    int v = __builtin_amdgcn_readfirstlane(tile * kTileViews + w);
+    bool valid = tile < ntiles && v < a.nviews;  // wave-uniform; the loop holds no workgroup barrier
+    if (valid) fetch(v);
+    {   // Four stores that the range check drops.  Inside the loop the loads of a view are followed by
+        // the four result stores of the view before; giving the first view the same number of younger
+        // stores lets the wait before the point phase be "all but four" on both paths instead of "all".
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        auto none = __builtin_amdgcn_make_buffer_rsrc(blk, 0, 0, 0x00020000);
+#pragma unroll
+        for (int r = 0; r < 4; r++) __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, none, 0x7fff0000 + 64 * r + lane, 0, 0);
+    }
+    const double2* const lds2r = reinterpret_cast<const double2*>(lds_dyn);
+    double2* const lds2 = reinterpret_cast<double2*>(lds_dyn);
+    const int src = ((jt + col * RS) >> 1) + rq;
+    const int dst = (jt >> 1) + lane;  // in double2 units; RS is even
+    int dirty = CH;                    // rows of points [n, dirty) hold an earlier view's values
+    while (valid) {
+        const int n = np;              // the launcher guarantees np <= CH <= 64
+        const int tile_cur = tile;
+        if (lane < n && !(dbg & 1)) {
+            double qd[13];
+#pragma unroll
+            for (int k = 0; k < 13; k++) {
+                unsigned lo = __builtin_amdgcn_readlane(qword, 2 * k), hi = __builtin_amdgcn_readlane(qword, 2 * k + 1);
+                qd[k] = __hiloint2double((int)hi, (int)lo);
+            }
+            PoseConst q;
+            q.ax[0] = qd[0], q.ax[1] = qd[1], q.ax[2] = qd[2], q.c = qd[3], q.c1 = qd[4], q.s = qd[5];
+            q.b1 = qd[6], q.b2 = qd[7], q.b3 = qd[8], q.b4 = qd[9], q.t[0] = qd[10], q.t[1] = qd[11], q.t[2] = qd[12];
+            float X = bX, Y = bY, Z = bZ;
+            if constexpr (!SHARED) {
+                const float* ob = a.obj + 3 * (size_t)(first + lane);
+                X = ob[0], Y = ob[1], Z = ob[2];
+            }
+            PointOut<M> o;
+            double jex[6], jey[6];
+            point_jacobian<M>(q, cp, (double)X, (double)Y, (double)Z, (double)mpt.x, (double)mpt.y, o, jex, jey);
+#pragma unroll
+            for (int i = 0; i < NC; i++) lds2[dst + ((i * RS) >> 1)] = make_double2(o.jx[i], o.jy[i]);
+#pragma unroll
+            for (int b = 0; b < 6; b++) lds2[dst + (((CPOSE + b) * RS) >> 1)] = make_double2(jex[b], jey[b]);
+            lds2[dst + ((CRES * RS) >> 1)] = make_double2(o.ex, o.ey);
+        }
+        if (n < dirty) {  // rows past this view's last point must read as zero (wave-uniform branch)
+            if (lane >= n && lane < dirty) {
+#pragma unroll
+                for (int c = 0; c < NCOL; c++) lds2[dst + ((c * RS) >> 1)] = make_double2(0., 0.);
+            }
+        }
+        dirty = n;
+        // the next view's loads go out here, ahead of the matrix phase
+        tile += gridDim.x;
+        v = __builtin_amdgcn_readfirstlane(tile * kTileViews + w);
+        valid = tile < ntiles && v < a.nviews;
+        if (valid) fetch(v);
+        __builtin_amdgcn_wave_barrier();
+        // eight rows per step: this lane feeds rows 8m + 2rq and 8m + 2rq + 1 of column `col`;
+        // the read of step m + 1 is in flight while step m multiplies
+        const int npairs = (dbg & 2) ? 0 : (2 * n + 15) >> 4;
+        double4_t acc = {0., 0., 0., 0.};
+        // sixteen rows per trip, the two operand pairs in alternating registers (no copies); the read
+        // of the step after is in flight while a step multiplies.  CH is a multiple of 8, so the rows
+        // up to the next multiple of 16 exist and are zero.
+        {
+            const int last = src + 8 * (npairs - 1) + 4;
+            int nxt = src + 4;
+            double2 pa = lds2r[src];
+            for (int k = 0; k < npairs; k++) {
+                double2 pb = lds2r[nxt];
+                nxt = nxt + 4 < last ? nxt + 4 : last;
+                __builtin_amdgcn_sched_barrier(0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.x, pa.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.y, pa.y, acc, 0, 0, 0);
+                pa = lds2r[nxt];
+                nxt = nxt + 4 < last ? nxt + 4 : last;
+                __builtin_amdgcn_sched_barrier(0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pb.x, pb.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pb.y, pb.y, acc, 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // the reads are done before the next view overwrites the buffer
+        usum += acc;
+        // Unconditional buffer stores: lanes whose register holds nothing to keep carry an offset
+        // past the tile, which the range check drops.  (Stores under a branch would hide their
+        // number from the wait-count bookkeeping and make the next view wait for all of them.)
+        auto rsrc = __builtin_amdgcn_make_buffer_rsrc(blk + (size_t)tile_cur * NB * kTileViews, 0,
+                                                      NB * kTileViews * (int)sizeof(double), 0x00020000);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            double d = acc[r];
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, d), rsrc, (dbg & 4) ? 0x7fffffff : voff[r], 0, 0);
+        }
+    }
+    double* po = part + (size_t)(blockIdx.x * kWaves + w) * NR;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        if (qu[r] >= 0) po[qu[r]] = usum[r];
 }
 
 // ---- per-view elimination --------------------------------------------------------------------
@@ -365,21 +532,21 @@ __global__ __launch_bounds__(kBlock, CCALIB_VIEW_MINWAVES) void k_jac_view(PassA
 // sum W V'^-1 W^T over its 64 views (NC(NC+1)/2 values) followed by sum W V'^-1 ge (NC values).
 template <int NC>
 __global__ __launch_bounds__(64) void k_schur(const double* blk, int npad, int nviews, double lambda, double* part) {
-    constexpr int NS = NC * (NC + 1) / 2 + NC;
+    constexpr int NS = NC * (NC + 1) / 2 + NC, NB = 27 + 6 * NC;
     int v = blockIdx.x * 64 + threadIdx.x;
     bool live = v < nviews;
     int vv = live ? v : nviews - 1;
     double Vu[21], L[21], invd[6], y[6], Z[NC][6];
 #pragma unroll
-    for (int k = 0; k < 21; k++) Vu[k] = blk[(size_t)k * npad + vv];
+    for (int k = 0; k < 21; k++) Vu[k] = blk[blk_index(NB, k, vv)];
 #pragma unroll
-    for (int k = 0; k < 6; k++) y[k] = blk[(size_t)(21 + k) * npad + vv];
+    for (int k = 0; k < 6; k++) y[k] = blk[blk_index(NB, 21 + k, vv)];
     bool ok = chol6(Vu, lambda, L, invd) && live;
     chol6_fwd(L, invd, y);
 #pragma unroll
     for (int i = 0; i < NC; i++) {
 #pragma unroll
-        for (int b = 0; b < 6; b++) Z[i][b] = blk[(size_t)(27 + 6 * i + b) * npad + vv];
+        for (int b = 0; b < 6; b++) Z[i][b] = blk[blk_index(NB, 27 + 6 * i + b, vv)];
         chol6_fwd(L, invd, Z[i]);  // Z_i = L^-1 W_i^T, so W V'^-1 W^T = Z Z^T
     }
     double* out = part + (size_t)blockIdx.x * NS;
@@ -410,19 +577,20 @@ __global__ __launch_bounds__(64) void k_schur(const double* blk, int npad, int n
 template <int NC>
 __global__ __launch_bounds__(64) void k_backsub(const double* blk, int npad, int nviews, double lambda, DeltaC dc,
                                                 const double* pose_prev, double* pose_cur, double* part) {
+    constexpr int NB = 27 + 6 * NC;
     int v = blockIdx.x * 64 + threadIdx.x;
     bool live = v < nviews;
     int vv = live ? v : nviews - 1;
     double Vu[21], L[21], invd[6], rhs[6];
 #pragma unroll
-    for (int k = 0; k < 21; k++) Vu[k] = blk[(size_t)k * npad + vv];
+    for (int k = 0; k < 21; k++) Vu[k] = blk[blk_index(NB, k, vv)];
 #pragma unroll
-    for (int k = 0; k < 6; k++) rhs[k] = blk[(size_t)(21 + k) * npad + vv];
+    for (int k = 0; k < 6; k++) rhs[k] = blk[blk_index(NB, 21 + k, vv)];
 #pragma unroll
     for (int i = 0; i < NC; i++) {
         double d = dc.v[i];
 #pragma unroll
-        for (int b = 0; b < 6; b++) rhs[b] -= blk[(size_t)(27 + 6 * i + b) * npad + vv] * d;
+        for (int b = 0; b < 6; b++) rhs[b] -= blk[blk_index(NB, 27 + 6 * i + b, vv)] * d;
     }
     bool ok = chol6(Vu, lambda, L, invd);
     chol6_fwd(L, invd, rhs);
@@ -490,6 +658,17 @@ static void launch_jac_view(const PassArgs& a, const CamParams& cp, int grid, do
         k_jac_view<M, decltype(g)::value><<<dim3(grid), dim3(kBlock), a.lds_bytes, st>>>(a, cp, blk, npad);
     });
 }
+template <class M>
+static void launch_jac_fused(const PassArgs& a, const CamParams& cp, const double* pc, int grid, double* blk, double* part,
+                             hipStream_t st) {
+    FusedGeom g = fused_geom(a.maxnp, a.shared_board != 0, a.board_np);
+    int dbg = 0;
+    if (const char* e = std::getenv("CCALIB_FUSED_DBG")) dbg = std::atoi(e);
+    if (a.shared_board)
+        k_jac_fused<M, true><<<dim3(grid), dim3(kBlock), g.lds_bytes, st>>>(a, cp, a.off, pc, blk, part, g.RS, g.CH, dbg);
+    else
+        k_jac_fused<M, false><<<dim3(grid), dim3(kBlock), g.lds_bytes, st>>>(a, cp, a.off, pc, blk, part, g.RS, g.CH, dbg);
+}
 template <int NC>
 static void launch_schur(const double* blk, int npad, int nviews, double lambda, double* part, hipStream_t st) {
     hipLaunchKernelGGL(k_schur<NC>, dim3((nviews + 63) / 64), dim3(64), 0, st, blk, npad, nviews, lambda, part);
@@ -501,12 +680,20 @@ static void launch_backsub(const double* blk, int npad, int nviews, double lambd
                        pose_prev, pose_cur, part);
 }
 
+template <class M>
+constexpr auto fused_or_null() -> decltype(&launch_jac_fused<M>) {
+    if constexpr (M::NC + 7 <= 16)
+        return &launch_jac_fused<M>;
+    else
+        return nullptr;
+}
+
 #define CCALIB_MODEL_ENTRY(MASK, ASPECT, RAT)                                                         \
     {                                                                                                 \
         MASK, ASPECT, RAT, Model<MASK, ASPECT, RAT>::NC, Model<MASK, ASPECT, RAT>::NRED_U,            \
             Model<MASK, ASPECT, RAT>::NBLK, launch_jac_shared<Model<MASK, ASPECT, RAT>>,              \
             launch_jac_view<Model<MASK, ASPECT, RAT>>, launch_schur<Model<MASK, ASPECT, RAT>::NC>,    \
-            launch_backsub<Model<MASK, ASPECT, RAT>::NC>                                              \
+            launch_backsub<Model<MASK, ASPECT, RAT>::NC>, fused_or_null<Model<MASK, ASPECT, RAT>>()   \
     }
 
 // Column sets built into this library.  The first three are the free sets of the reference's
@@ -556,6 +743,21 @@ void launch_reproj(const PassArgs& a, const CamParams& cp, bool rational, int gr
 
 void launch_colsum(const double* part, int nrows, int n, double* out, hipStream_t st) {
     hipLaunchKernelGGL(k_colsum, dim3(n), dim3(kBlock), 0, st, part, nrows, n, out);
+}
+
+void launch_pose_const(const double* pose, int nviews, double* pc, hipStream_t st) {
+    hipLaunchKernelGGL(k_pose_const, dim3((nviews + 63) / 64), dim3(64), 0, st, pose, nviews, pc);
+}
+
+FusedGeom fused_geom(int maxnp, bool shared_board, int board_np) {
+    FusedGeom g;
+    g.CH = maxnp >= 64 ? 64 : (maxnp + 7) / 8 * 8;
+    g.RS = 2 * g.CH;
+    while (!(g.RS % 32 == 2 || g.RS % 32 == 14 || g.RS % 32 == 18 || g.RS % 32 == 30)) g.RS += 2;
+    size_t board_f = shared_board ? (size_t)(3 * board_np + 3) / 4 * 4 : 0;
+    g.lds_bytes = (unsigned)(sizeof(float) * board_f + sizeof(double) * kWaves * 16 * (size_t)g.RS);
+    if (const char* e = std::getenv("CCALIB_LDS_PAD")) g.lds_bytes = std::max<unsigned>(g.lds_bytes, std::atoi(e));
+    return g;
 }
 
 int pass_block_size() { return kBlock; }

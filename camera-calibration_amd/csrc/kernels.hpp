@@ -19,6 +19,28 @@ struct PassArgs {
     unsigned lds_bytes;  // dynamic LDS per workgroup, from pass_lds_bytes()
 };
 
+// Per-view normal-equation blocks in HBM: views are grouped in tiles of kTileViews (the views one
+// workgroup of the Jacobian pass owns at a time); a tile holds its NB quantities quantity-major,
+// so one workgroup writes one contiguous tile and a lane-per-view consumer reads, for a fixed
+// quantity, runs of kTileViews consecutive doubles.
+//   quantity q: 0..20 V upper triangle (tri6), 21..26 ge, 27 + 6*i + b = W[i][b]
+constexpr int kTileViews = 4;
+__host__ __device__ inline size_t blk_index(int NB, int q, int v) {
+    return ((size_t)(v / kTileViews) * NB + q) * kTileViews + (v % kTileViews);
+}
+
+// Pose in the 13-double form the fused Jacobian kernel reads through the scalar cache
+// (ax[3] c c1 s b1 b2 b3 b4 t[3], padded to 16 doubles per view).
+constexpr int kPoseConstStride = 16;
+void launch_pose_const(const double* pose, int nviews, double* pc, hipStream_t);
+
+// LDS geometry of the fused Jacobian kernel: CH points per chunk, RS doubles between columns.
+struct FusedGeom {
+    int CH, RS;
+    unsigned lds_bytes;
+};
+FusedGeom fused_geom(int maxnp, bool shared_board, int board_np);
+
 struct DeltaC {
     double v[I_NMODEL];  // step of the kernel's intrinsic columns (0 for columns not optimised)
 };
@@ -32,6 +54,10 @@ struct ModelOps {
     void (*schur)(const double* blk, int npad, int nviews, double lambda, double* part, hipStream_t);
     void (*backsub)(const double* blk, int npad, int nviews, double lambda, const DeltaC&, const double* pose_prev,
                     double* pose_cur, double* part, hipStream_t);
+    // whole Jacobian pass in one kernel (shared block partials: 4 * grid rows of NRED_U); null when the
+    // column set does not fit the 16-wide matrix tile
+    void (*jac_fused)(const PassArgs&, const CamParams&, const double* pc, int grid, double* blk, double* part,
+                      hipStream_t);
     int col(int i) const {  // i-th produced column -> intrinsic index
         int seen = 0;
         for (int q = 0; q < I_NMODEL; q++)

@@ -46,6 +46,8 @@ struct ccalib_solver {
     int G = 4, nblk64 = 0, npad = 0;
     int grid_view = 0;  // per-view kernels: every wavefront does one round
     int grid_red = 0;   // reducing kernels: fewer workgroups, several rounds each, one reduction at the end
+    int grid_fused = 0; // fused Jacobian kernel: workgroups striding over tiles of kTileViews views
+    bool use_fused = true;
     unsigned lds_bytes = 0;
     hipStream_t stream = nullptr;
     float* d_obj = nullptr;
@@ -55,6 +57,7 @@ struct ccalib_solver {
     double* d_pose3 = nullptr;                              // stereo: composed camera-1 poses
     double* d_cmp = nullptr;                                // stereo: per-view composition Jacobians (SoA)
     double* d_blk[2] = {nullptr, nullptr};
+    double* d_pc = nullptr;  // nviews x kPoseConstStride: poses in the form the fused Jacobian kernel reads
     double* d_part = nullptr;
     size_t part_cap = 0;
     double* d_red = nullptr;
@@ -202,10 +205,18 @@ int be_jac(void* user, const double* shared, double lambda_hint, double* U, doub
         const ModelOps* m = s->ops[c];
         CamParams cp = cam_params(s->intr[c], s->aspect[c]);
         PassArgs a = pass_args(s, c, cam_pose(s, c));
-        if ((rc = ensure_part(s, (size_t)s->grid_red * m->NRED_U))) return rc;
-        m->jac_shared(a, cp, s->grid_red, s->d_part, s->stream);
-        launch_colsum(s->d_part, s->grid_red, m->NRED_U, s->d_red + ofs, s->stream);
-        m->jac_view(a, cp, s->grid_view, s->d_blk[c], s->npad, s->stream);
+        if (m->jac_fused && s->use_fused) {
+            int rows = s->grid_fused * kTileViews;
+            if ((rc = ensure_part(s, (size_t)rows * m->NRED_U))) return rc;
+            launch_pose_const(a.pose, s->nviews, s->d_pc, s->stream);
+            m->jac_fused(a, cp, s->d_pc, s->grid_fused, s->d_blk[c], s->d_part, s->stream);
+            launch_colsum(s->d_part, rows, m->NRED_U, s->d_red + ofs, s->stream);
+        } else {
+            if ((rc = ensure_part(s, (size_t)s->grid_red * m->NRED_U))) return rc;
+            m->jac_shared(a, cp, s->grid_red, s->d_part, s->stream);
+            launch_colsum(s->d_part, s->grid_red, m->NRED_U, s->d_red + ofs, s->stream);
+            m->jac_view(a, cp, s->grid_view, s->d_blk[c], s->npad, s->stream);
+        }
         cam_ofs[c] = ofs;
         ofs += m->NRED_U;
     }
@@ -422,6 +433,12 @@ int ccalib_solver_create(ccalib_solver** out, int device, int ncams, int nviews,
     s->grid_view = (nviews + views_per_block - 1) / views_per_block;
     s->grid_red = std::min(s->grid_view, 512);
     if (const char* e = std::getenv("CCALIB_GRID_RED")) s->grid_red = std::max(1, std::min(s->grid_view, std::atoi(e)));
+    s->grid_fused = std::min((nviews + kTileViews - 1) / kTileViews, 512);  // two workgroups per CU
+    if (const char* e = std::getenv("CCALIB_GRID_FUSED"))
+        s->grid_fused = std::max(1, std::min((nviews + kTileViews - 1) / kTileViews, std::atoi(e)));
+    if (const char* e = std::getenv("CCALIB_NO_FUSED")) s->use_fused = std::atoi(e) == 0;
+    // one wavefront evaluates a whole view at once, one point per lane
+    if (s->maxnp > 64 || fused_geom(s->maxnp, s->shared_board, s->board_np).lds_bytes > 64 * 1024) s->use_fused = false;
     s->nblk64 = (nviews + 63) / 64;
     s->npad = (nviews + 63) / 64 * 64;
     HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
@@ -438,6 +455,7 @@ int ccalib_solver_create(ccalib_solver** out, int device, int ncams, int nviews,
     HIP_TRY(hipMalloc(&s->d_pose_prev, sizeof(double) * 6 * nviews));
     HIP_TRY(hipMalloc(&s->d_pose_cur, sizeof(double) * 6 * nviews));
     HIP_TRY(hipMemset(s->d_pose_prev, 0, sizeof(double) * 6 * nviews));
+    HIP_TRY(hipMalloc(&s->d_pc, sizeof(double) * kPoseConstStride * nviews));
     if (ncams == 2) {
         HIP_TRY(hipMalloc(&s->d_pose3, sizeof(double) * 6 * nviews));
         HIP_TRY(hipMalloc(&s->d_cmp, sizeof(double) * kCmpRows * s->npad));
@@ -455,7 +473,7 @@ void ccalib_solver_destroy(ccalib_solver* s) {
     if (s->comm) ncclCommDestroy(s->comm);
     (void)hipFree(s->d_obj), (void)hipFree(s->d_off), (void)hipFree(s->d_img[0]), (void)hipFree(s->d_img[1]);
     (void)hipFree(s->d_pose_prev), (void)hipFree(s->d_pose_cur), (void)hipFree(s->d_pose3), (void)hipFree(s->d_cmp);
-    (void)hipFree(s->d_blk[0]), (void)hipFree(s->d_blk[1]), (void)hipFree(s->d_part), (void)hipFree(s->d_red);
+    (void)hipFree(s->d_pc), (void)hipFree(s->d_blk[0]), (void)hipFree(s->d_blk[1]), (void)hipFree(s->d_part), (void)hipFree(s->d_red);
     if (s->h_red) (void)hipHostFree(s->h_red);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
@@ -605,11 +623,11 @@ int ccalib_solver_fetch_blocks(ccalib_solver* s, double* V, double* W, double* g
     for (int v = 0; v < s->nviews; v++) {
         int k = 0;
         for (int a = 0; a < 6; a++)
-            for (int b = a; b < 6; b++, k++) V[(size_t)v * 36 + a * 6 + b] = V[(size_t)v * 36 + b * 6 + a] = h[(size_t)k * s->npad + v];
-        for (int a = 0; a < 6; a++) ge[(size_t)v * 6 + a] = h[(size_t)(21 + a) * s->npad + v];
+            for (int b = a; b < 6; b++, k++) V[(size_t)v * 36 + a * 6 + b] = V[(size_t)v * 36 + b * 6 + a] = h[blk_index(m->NBLK, k, v)];
+        for (int a = 0; a < 6; a++) ge[(size_t)v * 6 + a] = h[blk_index(m->NBLK, 21 + a, v)];
         for (int i = 0; i < ns * 6; i++) W[(size_t)v * ns * 6 + i] = 0;
         for (int i = 0; i < m->NC; i++)
-            for (int b = 0; b < 6; b++) W[((size_t)v * ns + m->col(i)) * 6 + b] = h[(size_t)(27 + 6 * i + b) * s->npad + v];
+            for (int b = 0; b < 6; b++) W[((size_t)v * ns + m->col(i)) * 6 + b] = h[blk_index(m->NBLK, 27 + 6 * i + b, v)];
     }
     return CCALIB_OK;
 }
@@ -634,14 +652,22 @@ int ccalib_solver_time_kernels(ccalib_solver* s, int reps, double ms[3]) {
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     const ModelOps* m = s->ops[0];
-    int rc = ensure_part(s, (size_t)s->grid_red * m->NRED_U);
+    const bool fused = m->jac_fused && s->use_fused;
+    int rc = ensure_part(s, (size_t)std::max(s->grid_red, s->grid_fused * kTileViews) * m->NRED_U);
     if (rc) return rc;
     CamParams cp = cam_params(s->intr[0], s->aspect[0]);
     PassArgs a = pass_args(s, 0, s->d_pose_cur);
+    if (fused) launch_pose_const(a.pose, s->nviews, s->d_pc, s->stream);
     for (int which = 0; which < 3; which++) {
+        if (which == 0 && fused) {  // the fused kernel does the shared block as well
+            ms[0] = 0.;
+            continue;
+        }
         auto launch = [&]() {
             if (which == 0)
                 m->jac_shared(a, cp, s->grid_red, s->d_part, s->stream);
+            else if (which == 1 && fused)
+                m->jac_fused(a, cp, s->d_pc, s->grid_fused, s->d_blk[0], s->d_part, s->stream);
             else if (which == 1)
                 m->jac_view(a, cp, s->grid_view, s->d_blk[0], s->npad, s->stream);
             else

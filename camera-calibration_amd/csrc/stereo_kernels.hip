@@ -13,6 +13,7 @@
 #include "stereo_kernels.hpp"
 
 #include "device_math.hpp"
+#include "kernels.hpp"
 
 namespace ccalib {
 
@@ -187,9 +188,9 @@ __global__ __launch_bounds__(64) void k_stereo_lr_sums(const double* blk1, const
     load_cmp(cmp, npad, vv, lr, c);
     double u[21], V3[6][6], ge3[6];
 #pragma unroll
-    for (int k = 0; k < 21; k++) u[k] = blk1[(size_t)k * npad + vv];
+    for (int k = 0; k < 21; k++) u[k] = blk1[blk_index((27 + 6 * NC1), k, vv)];
 #pragma unroll
-    for (int k = 0; k < 6; k++) ge3[k] = blk1[(size_t)(21 + k) * npad + vv];
+    for (int k = 0; k < 6; k++) ge3[k] = blk1[blk_index((27 + 6 * NC1), 21 + k, vv)];
     unpack_sym6(u, V3);
     double N[6][6], BtN[6][6];
 #pragma unroll
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(64) void k_stereo_lr_sums(const double* blk1, const
     for (int i = 0; i < NC1; i++) {
         double w[6], wb[6];
 #pragma unroll
-        for (int b = 0; b < 6; b++) w[b] = blk1[(size_t)(27 + 6 * i + b) * npad + vv];
+        for (int b = 0; b < 6; b++) w[b] = blk1[blk_index((27 + 6 * NC1), 27 + 6 * i + b, vv)];
         row_times_B(c, w, wb);
 #pragma unroll
         for (int b = 0; b < 6; b++) {
@@ -239,13 +240,14 @@ struct ViewSys {
     double Vu[21], ge[6];
     double M[6][6];
 };
+template <int NC0, int NC1>
 __device__ __forceinline__ void assemble_view(const double* blk0, const double* blk1, int npad, int vv, const Cmp& c,
                                               ViewSys& s) {
     double u[21], V3[6][6], ge3[6], AtM[6][6];
 #pragma unroll
-    for (int k = 0; k < 21; k++) u[k] = blk1[(size_t)k * npad + vv];
+    for (int k = 0; k < 21; k++) u[k] = blk1[blk_index((27 + 6 * NC1), k, vv)];
 #pragma unroll
-    for (int k = 0; k < 6; k++) ge3[k] = blk1[(size_t)(21 + k) * npad + vv];
+    for (int k = 0; k < 6; k++) ge3[k] = blk1[blk_index((27 + 6 * NC1), 21 + k, vv)];
     unpack_sym6(u, V3);
 #pragma unroll
     for (int a = 0; a < 6; a++) row_times_A(c, V3[a], s.M[a]);
@@ -253,12 +255,12 @@ __device__ __forceinline__ void assemble_view(const double* blk0, const double* 
 #pragma unroll
     for (int a = 0; a < 6; a++)
 #pragma unroll
-        for (int b = a; b < 6; b++) s.Vu[tri6(a, b)] = blk0[(size_t)tri6(a, b) * npad + vv] + AtM[a][b];
+        for (int b = a; b < 6; b++) s.Vu[tri6(a, b)] = blk0[blk_index((27 + 6 * NC0), tri6(a, b), vv)] + AtM[a][b];
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-        s.ge[a] = blk0[(size_t)(21 + a) * npad + vv] + c.Ar[a] * ge3[0] + c.Ar[3 + a] * ge3[1] + c.Ar[6 + a] * ge3[2];
+        s.ge[a] = blk0[blk_index((27 + 6 * NC0), 21 + a, vv)] + c.Ar[a] * ge3[0] + c.Ar[3 + a] * ge3[1] + c.Ar[6 + a] * ge3[2];
         s.ge[3 + a] =
-            blk0[(size_t)(24 + a) * npad + vv] + c.R2[a] * ge3[3] + c.R2[3 + a] * ge3[4] + c.R2[6 + a] * ge3[5];
+            blk0[blk_index((27 + 6 * NC0), 24 + a, vv)] + c.R2[a] * ge3[3] + c.R2[3 + a] * ge3[4] + c.R2[6 + a] * ge3[5];
     }
 }
 
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(64) void k_stereo_schur(const double* blk0, const d
     Cmp c;
     load_cmp(cmp, npad, vv, lr, c);
     ViewSys s;
-    assemble_view(blk0, blk1, npad, vv, c, s);
+    assemble_view<NC0, NC1>(blk0, blk1, npad, vv, c, s);
     double L[21], invd[6], y[6], Z[KC][6];
     bool ok = chol6(s.Vu, lambda, L, invd) && live;
 #pragma unroll
@@ -292,14 +294,14 @@ __global__ __launch_bounds__(64) void k_stereo_schur(const double* blk0, const d
 #pragma unroll
     for (int i = 0; i < NC0; i++) {
 #pragma unroll
-        for (int b = 0; b < 6; b++) Z[6 + i][b] = blk0[(size_t)(27 + 6 * i + b) * npad + vv];
+        for (int b = 0; b < 6; b++) Z[6 + i][b] = blk0[blk_index((27 + 6 * NC0), 27 + 6 * i + b, vv)];
         chol6_fwd(L, invd, Z[6 + i]);
     }
 #pragma unroll
     for (int i = 0; i < NC1; i++) {
         double w[6];
 #pragma unroll
-        for (int b = 0; b < 6; b++) w[b] = blk1[(size_t)(27 + 6 * i + b) * npad + vv];
+        for (int b = 0; b < 6; b++) w[b] = blk1[blk_index((27 + 6 * NC1), 27 + 6 * i + b, vv)];
         row_times_A(c, w, Z[6 + NC0 + i]);
         chol6_fwd(L, invd, Z[6 + NC0 + i]);
     }
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(64) void k_stereo_backsub(const double* blk0, const
     Cmp c;
     load_cmp(cmp, npad, vv, lr, c);
     ViewSys s;
-    assemble_view(blk0, blk1, npad, vv, c, s);
+    assemble_view<NC0, NC1>(blk0, blk1, npad, vv, c, s);
     double rhs[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) rhs[k] = s.ge[k];
@@ -352,13 +354,13 @@ __global__ __launch_bounds__(64) void k_stereo_backsub(const double* blk0, const
 #pragma unroll
     for (int i = 0; i < NC0; i++)
 #pragma unroll
-        for (int b = 0; b < 6; b++) rhs[b] -= blk0[(size_t)(27 + 6 * i + b) * npad + vv] * d.v[6 + i];
+        for (int b = 0; b < 6; b++) rhs[b] -= blk0[blk_index((27 + 6 * NC0), 27 + 6 * i + b, vv)] * d.v[6 + i];
     {
         double acc[6] = {0, 0, 0, 0, 0, 0}, wa[6];  // (sum_i d_i W3_i) A
 #pragma unroll
         for (int i = 0; i < NC1; i++)
 #pragma unroll
-            for (int b = 0; b < 6; b++) acc[b] += blk1[(size_t)(27 + 6 * i + b) * npad + vv] * d.v[6 + NC0 + i];
+            for (int b = 0; b < 6; b++) acc[b] += blk1[blk_index((27 + 6 * NC1), 27 + 6 * i + b, vv)] * d.v[6 + NC0 + i];
         row_times_A(c, acc, wa);
 #pragma unroll
         for (int b = 0; b < 6; b++) rhs[b] -= wa[b];

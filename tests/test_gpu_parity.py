@@ -320,7 +320,9 @@ def test_cpp_dropin_header_end_to_end():
     assert r["mono_rms"][0] < 2e-4                       # float32 image points: ~1e-5 px quantisation
     assert np.allclose(r["mono_K"], [812.5, 806.25, 322.0, 238.5], rtol=1e-4)
     assert np.allclose(r["mono_D"], [-0.21, 0.09, 0.0007, -0.0004, -0.015], atol=2e-3)
-    assert abs(r["reproj_rms"][0] - r["mono_rms"][0]) <= 1e-6 * max(r["mono_rms"][0], 1e-12) + 1e-9
+    # the re-check rounds projections to float32 as cv::projectPoints into vector<Point2f> does, so on
+    # noise-free input the two figures only agree to the float32 spacing of a pixel coordinate (~3e-5)
+    assert abs(r["reproj_rms"][0] - r["mono_rms"][0]) < 3e-5
     assert r["stereo_rms"][0] < 2e-4
     assert np.allclose(r["stereo_T"], [-120.0, 1.5, 2.5], atol=2e-2)
     assert np.allclose(r["stereo_K2"], [798.0, 801.5, 316.5, 244.0], rtol=1e-4)

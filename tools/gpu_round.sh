@@ -1,0 +1,7 @@
+set -e
+mkdir -p gpurun_out
+timeout -k 10 700 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/t.log 2>&1 || { tail -40 gpurun_out/t.log; exit 1; }
+tail -3 gpurun_out/t.log
+timeout -k 10 120 python tools/kernel_bench.py
+CCALIB_NO_FUSED=1 timeout -k 10 120 python tools/kernel_bench.py
+timeout -k 10 300 python bench.py --steps 20 --warmup 3 --no-cpu

@@ -10,7 +10,8 @@ def main():
     views = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     pkg = ge.load_package(); synth = pkg.synth
-    obj = synth.chessboard(9, 6, 25.0)
+    bw, bh = (int(x) for x in os.environ.get('BOARD', '9x6').split('x'))
+    obj = synth.chessboard(bw, bh, 25.0)
     ms = synth.make_views(obj, views, 0xC0FFEE + 4)
     cam = ms.cam
     intr, mask, _ = pkg.mono_start(cam.K(), cam.dist(5), 0)
