@@ -36,7 +36,7 @@ JAC_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_double, C.P
                      C.POINTER(C.c_double), C.POINTER(C.c_double))
 REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_double),
                         C.POINTER(C.c_double))
-STEP_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_double),
+STEP_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double, C.c_double, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_double),
                       C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
 COMMIT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
 FIXUP_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double))

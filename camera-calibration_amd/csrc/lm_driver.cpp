@@ -166,7 +166,8 @@ extern "C" int ccalib_lm_run(const ccalib_backend* be, void* user, double* share
         }
         if (be->fixup) be->fixup(user, shared, prev.data());
         err_passes++;
-        return be->step_err(user, lambda, fidx.data(), nf, dsh.data(), shared, &dn2, &pn2, &err_out);
+        return be->step_err(user, lambda, lam(std::max(lambdaLg10 - 1, -16)), fidx.data(), nf, dsh.data(), shared, &dn2,
+                            &pn2, &err_out);
     };
 
     // STARTED -> CALC_J

@@ -55,8 +55,11 @@ struct ccalib_solver {
     float2* d_img[2] = {nullptr, nullptr};
     double *d_pose_prev = nullptr, *d_pose_cur = nullptr;  // camera-0 poses, nviews x 6
     double* d_pose3 = nullptr;                              // stereo: composed camera-1 poses
-    double* d_cmp = nullptr;                                // stereo: per-view composition Jacobians (SoA)
-    double* d_blk[2] = {nullptr, nullptr};
+    // The per-view blocks exist twice: `cur` holds the Jacobian the driver is stepping from, the other
+    // one receives the pass run ahead at a trial point (see be_step_err).
+    int cur = 0;
+    double* d_cmp[2] = {nullptr, nullptr};                  // stereo: per-view composition Jacobians (SoA), per buffer
+    double* d_blk[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [camera][buffer]
     double* d_pc = nullptr;  // nviews x kPoseConstStride: poses in the form the fused Jacobian kernel reads
     double* d_part = nullptr;
     size_t part_cap = 0;
@@ -71,7 +74,7 @@ struct ccalib_solver {
     double aspect[2] = {0, 0};
     bool same_focal = false;
     double lr[6] = {0, 0, 0, 0, 0, 0};
-    StereoLR lr_jac;  // relative pose the per-view blocks in HBM were computed at
+    StereoLR lr_jac[2];  // relative pose the per-view blocks of each buffer were computed at
     const ModelOps* ops[2] = {nullptr, nullptr};
     bool rational[2] = {false, false};
     double last_err = 0;
@@ -80,6 +83,15 @@ struct ccalib_solver {
     bool have_cached = false;
     double cached_lambda = 0;
     std::vector<double> cachedS;  // kernel-column space, see reduce()
+
+    // Jacobian pass run ahead at the last trial point (valid until the next pass or step)
+    bool speculate = true;
+    bool spec_valid = false;
+    double spec_shared[42];
+    std::vector<double> spec_U, spec_gs, spec_S;
+    double spec_err = 0, spec_lambda = 0;
+    int steps_since_jac = 0;
+    bool prev_rejected = false;
 
     // multi-GPU
     ncclComm_t comm = nullptr;
@@ -164,43 +176,45 @@ void store_shared(ccalib_solver* s, const double* shared) {
     }
 }
 
-// Stereo: camera-1 poses (and, for Jacobian passes, the composition derivatives) for the current
-// camera-0 poses and relative pose.
-int stereo_compose(ccalib_solver* s, bool with_jac) {
+// Stereo: camera-1 poses (and, for Jacobian passes, the composition derivatives, into buffer `buf`)
+// for the current camera-0 poses and relative pose.
+int stereo_compose(ccalib_solver* s, bool with_jac, int buf) {
     if (s->ncams != 2) return CCALIB_OK;
     StereoLR lr;
     for (int i = 0; i < 6; i++) lr.v[i] = s->lr[i];
-    launch_compose(s->d_pose_cur, lr, s->nviews, s->npad, s->d_pose3, with_jac ? s->d_cmp : nullptr, s->stream);
+    launch_compose(s->d_pose_cur, lr, s->nviews, s->npad, s->d_pose3, with_jac ? s->d_cmp[buf] : nullptr, s->stream);
     return CCALIB_OK;
 }
 
 // ---- the four backend operations --------------------------------------------------------------
 
-// Launches the Schur-sum kernels for `lambda` and appends their column sums to d_red at `ofs`.
-// Layout appended: upper triangle (kc(kc+1)/2) then right-hand side (kc), kc = kernel columns.
-int enqueue_schur(ccalib_solver* s, double lambda, int ofs) {
+// Launches the Schur-sum kernels of buffer `buf` for `lambda` and appends their column sums to d_red
+// at `ofs`.  Layout appended: upper triangle (kc(kc+1)/2) then right-hand side (kc), kc = kernel columns.
+int enqueue_schur(ccalib_solver* s, int buf, double lambda, int ofs) {
     int kc = s->kcols(), nsum = kc * (kc + 1) / 2 + kc;
     int rc = ensure_part(s, (size_t)s->nblk64 * nsum);
     if (rc) return rc;
     if (s->ncams == 1)
-        s->ops[0]->schur(s->d_blk[0], s->npad, s->nviews, lambda, s->d_part, s->stream);
-    else if (!launch_stereo_schur(s->ops[0]->NC, s->d_blk[0], s->d_blk[1], s->d_cmp, s->lr_jac, s->npad, s->nviews,
-                                  lambda, s->d_part, s->stream))
+        s->ops[0]->schur(s->d_blk[0][buf], s->npad, s->nviews, lambda, s->d_part, s->stream);
+    else if (!launch_stereo_schur(s->ops[0]->NC, s->d_blk[0][buf], s->d_blk[1][buf], s->d_cmp[buf], s->lr_jac[buf],
+                                  s->npad, s->nviews, lambda, s->d_part, s->stream))
         return set_error(CCALIB_ERR_UNSUPPORTED, "stereo column count %d is not built in", s->ops[0]->NC);
     launch_colsum(s->d_part, s->nblk64, nsum, s->d_red + ofs, s->stream);
     return CCALIB_OK;
 }
 
-int be_jac(void* user, const double* shared, double lambda_hint, double* U, double* gs, double* err) {
-    ccalib_solver* s = (ccalib_solver*)user;
-    store_shared(s, shared);
-    const int ns = s->ns();
-    std::memset(U, 0, sizeof(double) * ns * ns);
-    std::memset(gs, 0, sizeof(double) * ns);
-    int rc = stereo_compose(s, true);
+// Where the sums of one Jacobian pass sit in d_red / h_red.
+struct JacLayout {
+    int cam_ofs[2] = {0, 0};
+    int lr_ofs = 0, schur_ofs = 0, nsum = 0, end = 0;
+};
+
+// Enqueues a whole Jacobian pass at the solver's current parameters and trial poses into buffer
+// `buf`, with the Schur sums for `lambda_hint`; the reduced sums land in d_red from `ofs` on.
+int enqueue_jac(ccalib_solver* s, int buf, double lambda_hint, int ofs, JacLayout& L) {
+    int rc = stereo_compose(s, true, buf);
     if (rc) return rc;
-    for (int i = 0; i < 6; i++) s->lr_jac.v[i] = s->lr[i];
-    int ofs = 0, cam_ofs[2] = {0, 0};
+    for (int i = 0; i < 6; i++) s->lr_jac[buf].v[i] = s->lr[i];
     for (int c = 0; c < s->ncams; c++) {
         const ModelOps* m = s->ops[c];
         CamParams cp = cam_params(s->intr[c], s->aspect[c]);
@@ -209,41 +223,48 @@ int be_jac(void* user, const double* shared, double lambda_hint, double* U, doub
             int rows = s->grid_fused * kTileViews;
             if ((rc = ensure_part(s, (size_t)rows * m->NRED_U))) return rc;
             launch_pose_const(a.pose, s->nviews, s->d_pc, s->stream);
-            m->jac_fused(a, cp, s->d_pc, s->grid_fused, s->d_blk[c], s->d_part, s->stream);
+            m->jac_fused(a, cp, s->d_pc, s->grid_fused, s->d_blk[c][buf], s->d_part, s->stream);
             launch_colsum(s->d_part, rows, m->NRED_U, s->d_red + ofs, s->stream);
         } else {
             if ((rc = ensure_part(s, (size_t)s->grid_red * m->NRED_U))) return rc;
             m->jac_shared(a, cp, s->grid_red, s->d_part, s->stream);
             launch_colsum(s->d_part, s->grid_red, m->NRED_U, s->d_red + ofs, s->stream);
-            m->jac_view(a, cp, s->grid_view, s->d_blk[c], s->npad, s->stream);
+            m->jac_view(a, cp, s->grid_view, s->d_blk[c][buf], s->npad, s->stream);
         }
-        cam_ofs[c] = ofs;
+        L.cam_ofs[c] = ofs;
         ofs += m->NRED_U;
     }
-    int lr_ofs = ofs;
+    L.lr_ofs = ofs;
     if (s->ncams == 2) {
         // shared-block pieces that involve the relative pose: B^T V3 B (21), B^T ge3 (6), W3 B (NC1 x 6)
         int n = 27 + 6 * s->ops[1]->NC;
         if ((rc = ensure_part(s, (size_t)s->nblk64 * n))) return rc;
-        if (!launch_stereo_lr_sums(s->ops[1]->NC, s->d_blk[1], s->d_cmp, s->lr_jac, s->npad, s->nviews, s->d_part, s->stream))
+        if (!launch_stereo_lr_sums(s->ops[1]->NC, s->d_blk[1][buf], s->d_cmp[buf], s->lr_jac[buf], s->npad, s->nviews,
+                                   s->d_part, s->stream))
             return set_error(CCALIB_ERR_UNSUPPORTED, "stereo column count %d is not built in", s->ops[1]->NC);
         launch_colsum(s->d_part, s->nblk64, n, s->d_red + ofs, s->stream);
         ofs += n;
     }
-    int schur_ofs = ofs;
-    int kc = s->kcols(), nsum = kc * (kc + 1) / 2 + kc;
-    if ((rc = enqueue_schur(s, lambda_hint, ofs))) return rc;
-    ofs += nsum;
+    L.schur_ofs = ofs;
+    int kc = s->kcols();
+    L.nsum = kc * (kc + 1) / 2 + kc;
+    if ((rc = enqueue_schur(s, buf, lambda_hint, ofs))) return rc;
+    ofs += L.nsum;
+    L.end = ofs;
     if (ofs > ccalib_solver::kRedCap) return set_error(CCALIB_ERR_STATE, "reduction buffer too small");
-    if ((rc = finish_reduction(s, ofs))) return rc;
-    s->cachedS.assign(s->h_red + schur_ofs, s->h_red + schur_ofs + nsum);
-    s->cached_lambda = lambda_hint;
-    s->have_cached = true;
+    return CCALIB_OK;
+}
 
+// Unpacks the sums of a finished pass from h_red: shared block U (ns x ns, upper triangle), its
+// gradient, the residual sum and the Schur sums.
+void parse_jac(const ccalib_solver* s, const JacLayout& L, double* U, double* gs, double* err, std::vector<double>& S) {
+    const int ns = s->ns();
+    std::memset(U, 0, sizeof(double) * ns * ns);
+    std::memset(gs, 0, sizeof(double) * ns);
     double e = 0;
     for (int c = 0; c < s->ncams; c++) {
         const ModelOps* m = s->ops[c];
-        const double* r = s->h_red + cam_ofs[c];
+        const double* r = s->h_red + L.cam_ofs[c];
         int base = s->ncams == 1 ? 0 : 6 + 18 * c;
         int k = 0;
         for (int i = 0; i < m->NC; i++)
@@ -252,7 +273,7 @@ int be_jac(void* user, const double* shared, double lambda_hint, double* U, doub
         e += r[k];
     }
     if (s->ncams == 2) {
-        const double* r = s->h_red + lr_ofs;
+        const double* r = s->h_red + L.lr_ofs;
         int k = 0;
         for (int i = 0; i < 6; i++)
             for (int j = i; j < 6; j++) U[(size_t)i * ns + j] = r[k++];
@@ -262,7 +283,38 @@ int be_jac(void* user, const double* shared, double lambda_hint, double* U, doub
             for (int b = 0; b < 6; b++) U[(size_t)b * ns + 24 + m1->col(i)] = r[k++];
     }
     *err = e;
-    s->last_err = e;
+    S.assign(s->h_red + L.schur_ofs, s->h_red + L.schur_ofs + L.nsum);
+}
+
+int be_jac(void* user, const double* shared, double lambda_hint, double* U, double* gs, double* err) {
+    ccalib_solver* s = (ccalib_solver*)user;
+    const int ns = s->ns();
+    s->prev_rejected = s->steps_since_jac > 1;
+    s->steps_since_jac = 0;
+    if (s->spec_valid && std::memcmp(shared, s->spec_shared, sizeof(double) * ns) == 0) {
+        // this pass was run ahead by the step that produced the point: adopt its buffer and sums
+        s->spec_valid = false;
+        s->cur ^= 1;
+        store_shared(s, shared);
+        std::memcpy(U, s->spec_U.data(), sizeof(double) * ns * ns);
+        std::memcpy(gs, s->spec_gs.data(), sizeof(double) * ns);
+        *err = s->spec_err;
+        s->last_err = s->spec_err;
+        s->cachedS = s->spec_S;
+        s->cached_lambda = s->spec_lambda;
+        s->have_cached = true;
+        return CCALIB_OK;
+    }
+    s->spec_valid = false;
+    store_shared(s, shared);
+    JacLayout L;
+    int rc = enqueue_jac(s, s->cur, lambda_hint, 0, L);
+    if (rc) return rc;
+    if ((rc = finish_reduction(s, L.end))) return rc;
+    parse_jac(s, L, U, gs, err, s->cachedS);
+    s->cached_lambda = lambda_hint;
+    s->have_cached = true;
+    s->last_err = *err;
     return CCALIB_OK;
 }
 
@@ -270,7 +322,7 @@ int be_reduce(void* user, double lambda, const int* fidx, int nf, double* Ssum, 
     ccalib_solver* s = (ccalib_solver*)user;
     int kc = s->kcols(), nsum = kc * (kc + 1) / 2 + kc;
     if (!(s->have_cached && s->cached_lambda == lambda)) {
-        int rc = enqueue_schur(s, lambda, 0);
+        int rc = enqueue_schur(s, s->cur, lambda, 0);
         if (rc) return rc;
         if ((rc = finish_reduction(s, nsum))) return rc;
         s->cachedS.assign(s->h_red, s->h_red + nsum);
@@ -294,10 +346,15 @@ int be_reduce(void* user, double lambda, const int* fidx, int nf, double* Ssum, 
     return CCALIB_OK;
 }
 
-int be_step_err(void* user, double lambda, const int* fidx, int nf, const double* dshared, const double* shared_new,
-                double* dnorm2, double* pnorm2, double* err) {
+// The trial point's residual sum comes either from the residual kernels or, when the step is
+// likely to be accepted, from a whole Jacobian pass run ahead into the spare buffer: the driver's
+// next call is then jac() at this same point, which be_jac answers without touching the GPU.
+// A rejected step only costs the extra work; the committed Jacobian stays in buffer `cur`.
+int be_step_err(void* user, double lambda, double lambda_next, const int* fidx, int nf, const double* dshared,
+                const double* shared_new, double* dnorm2, double* pnorm2, double* err) {
     ccalib_solver* s = (ccalib_solver*)user;
     int rc;
+    const int cur = s->cur;
     std::vector<double> dfull(s->ns(), 0.);
     for (int a = 0; a < nf; a++) dfull[fidx[a]] = dshared[a];
     if ((rc = ensure_part(s, (size_t)std::max(s->nblk64 * 2, s->grid_red)))) return rc;
@@ -305,32 +362,49 @@ int be_step_err(void* user, double lambda, const int* fidx, int nf, const double
         DeltaC dc;
         for (int k = 0; k < I_NMODEL; k++) dc.v[k] = 0;
         for (int k = 0; k < s->ops[0]->NC; k++) dc.v[k] = dfull[s->ops[0]->col(k)];
-        s->ops[0]->backsub(s->d_blk[0], s->npad, s->nviews, lambda, dc, s->d_pose_prev, s->d_pose_cur, s->d_part,
+        s->ops[0]->backsub(s->d_blk[0][cur], s->npad, s->nviews, lambda, dc, s->d_pose_prev, s->d_pose_cur, s->d_part,
                            s->stream);
     } else {
         StereoDelta sd;
         int kc = s->kcols();
         for (int k = 0; k < kStereoMaxCols; k++) sd.v[k] = k < kc ? dfull[s->kcol_to_shared(k)] : 0.;
-        if (!launch_stereo_backsub(s->ops[0]->NC, s->d_blk[0], s->d_blk[1], s->d_cmp, s->lr_jac, s->npad, s->nviews,
-                                   lambda, sd, s->d_pose_prev, s->d_pose_cur, s->d_part, s->stream))
+        if (!launch_stereo_backsub(s->ops[0]->NC, s->d_blk[0][cur], s->d_blk[1][cur], s->d_cmp[cur], s->lr_jac[cur],
+                                   s->npad, s->nviews, lambda, sd, s->d_pose_prev, s->d_pose_cur, s->d_part, s->stream))
             return set_error(CCALIB_ERR_UNSUPPORTED, "stereo column count %d is not built in", s->ops[0]->NC);
     }
     launch_colsum(s->d_part, s->nblk64, 2, s->d_red, s->stream);
-    // residual pass at the trial point
     store_shared(s, shared_new);
-    if ((rc = stereo_compose(s, false))) return rc;
-    for (int c = 0; c < s->ncams; c++) {
-        CamParams cp = cam_params(s->intr[c], s->aspect[c]);
-        PassArgs a = pass_args(s, c, cam_pose(s, c));
-        launch_err(a, cp, s->rational[c], s->grid_red, s->d_part, s->stream);
-        launch_colsum(s->d_part, s->grid_red, 1, s->d_red + 2 + c, s->stream);
+    const bool ahead = s->speculate && s->steps_since_jac == 0 && !s->prev_rejected;
+    s->steps_since_jac++;
+    s->spec_valid = false;
+    s->have_cached = false;
+    if (ahead) {
+        const int ns = s->ns();
+        JacLayout L;
+        if ((rc = enqueue_jac(s, cur ^ 1, lambda_next, 2, L))) return rc;
+        if ((rc = finish_reduction(s, L.end))) return rc;
+        s->spec_U.resize((size_t)ns * ns);
+        s->spec_gs.resize(ns);
+        parse_jac(s, L, s->spec_U.data(), s->spec_gs.data(), &s->spec_err, s->spec_S);
+        s->spec_lambda = lambda_next;
+        std::memcpy(s->spec_shared, shared_new, sizeof(double) * ns);
+        s->spec_valid = true;
+        *err = s->spec_err;
+    } else {
+        // residual pass at the trial point
+        if ((rc = stereo_compose(s, false, cur))) return rc;
+        for (int c = 0; c < s->ncams; c++) {
+            CamParams cp = cam_params(s->intr[c], s->aspect[c]);
+            PassArgs a = pass_args(s, c, cam_pose(s, c));
+            launch_err(a, cp, s->rational[c], s->grid_red, s->d_part, s->stream);
+            launch_colsum(s->d_part, s->grid_red, 1, s->d_red + 2 + c, s->stream);
+        }
+        if ((rc = finish_reduction(s, 2 + s->ncams))) return rc;
+        *err = s->h_red[2] + (s->ncams == 2 ? s->h_red[3] : 0.);
     }
-    if ((rc = finish_reduction(s, 2 + s->ncams))) return rc;
     *dnorm2 = s->h_red[0];
     *pnorm2 = s->h_red[1];
-    *err = s->h_red[2] + (s->ncams == 2 ? s->h_red[3] : 0.);
     s->last_err = *err;
-    s->have_cached = false;
     return CCALIB_OK;
 }
 
@@ -437,6 +511,7 @@ int ccalib_solver_create(ccalib_solver** out, int device, int ncams, int nviews,
     if (const char* e = std::getenv("CCALIB_GRID_FUSED"))
         s->grid_fused = std::max(1, std::min((nviews + kTileViews - 1) / kTileViews, std::atoi(e)));
     if (const char* e = std::getenv("CCALIB_NO_FUSED")) s->use_fused = std::atoi(e) == 0;
+    if (const char* e = std::getenv("CCALIB_NO_AHEAD")) s->speculate = std::atoi(e) == 0;
     // one wavefront evaluates a whole view at once, one point per lane
     if (s->maxnp > 64 || fused_geom(s->maxnp, s->shared_board, s->board_np).lds_bytes > 64 * 1024) s->use_fused = false;
     s->nblk64 = (nviews + 63) / 64;
@@ -458,7 +533,7 @@ int ccalib_solver_create(ccalib_solver** out, int device, int ncams, int nviews,
     HIP_TRY(hipMalloc(&s->d_pc, sizeof(double) * kPoseConstStride * nviews));
     if (ncams == 2) {
         HIP_TRY(hipMalloc(&s->d_pose3, sizeof(double) * 6 * nviews));
-        HIP_TRY(hipMalloc(&s->d_cmp, sizeof(double) * kCmpRows * s->npad));
+        for (int b = 0; b < 2; b++) HIP_TRY(hipMalloc(&s->d_cmp[b], sizeof(double) * kCmpRows * s->npad));
     }
     HIP_TRY(hipMalloc(&s->d_red, sizeof(double) * ccalib_solver::kRedCap));
     HIP_TRY(hipHostMalloc(&s->h_red, sizeof(double) * ccalib_solver::kRedCap));
@@ -472,8 +547,9 @@ void ccalib_solver_destroy(ccalib_solver* s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->comm) ncclCommDestroy(s->comm);
     (void)hipFree(s->d_obj), (void)hipFree(s->d_off), (void)hipFree(s->d_img[0]), (void)hipFree(s->d_img[1]);
-    (void)hipFree(s->d_pose_prev), (void)hipFree(s->d_pose_cur), (void)hipFree(s->d_pose3), (void)hipFree(s->d_cmp);
-    (void)hipFree(s->d_pc), (void)hipFree(s->d_blk[0]), (void)hipFree(s->d_blk[1]), (void)hipFree(s->d_part), (void)hipFree(s->d_red);
+    (void)hipFree(s->d_pose_prev), (void)hipFree(s->d_pose_cur), (void)hipFree(s->d_pose3);
+    for (int b = 0; b < 2; b++) (void)hipFree(s->d_cmp[b]), (void)hipFree(s->d_blk[0][b]), (void)hipFree(s->d_blk[1][b]);
+    (void)hipFree(s->d_pc), (void)hipFree(s->d_part), (void)hipFree(s->d_red);
     if (s->h_red) (void)hipHostFree(s->h_red);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
@@ -505,10 +581,11 @@ int ccalib_solver_set_start(ccalib_solver* s, const double* intr, const unsigned
     if (!m) return set_error(CCALIB_ERR_UNSUPPORTED, "no kernel column set covers mask 0x%x", need);
     for (int c = 0; c < s->ncams; c++) {
         s->rational[c] = rat;
-        if (m != s->ops[c] || !s->d_blk[c]) {
-            if (s->d_blk[c]) HIP_TRY(hipFree(s->d_blk[c]));
-            HIP_TRY(hipMalloc(&s->d_blk[c], sizeof(double) * (size_t)m->NBLK * s->npad));
-        }
+        for (int b = 0; b < 2; b++)
+            if (m != s->ops[c] || !s->d_blk[c][b]) {
+                if (s->d_blk[c][b]) HIP_TRY(hipFree(s->d_blk[c][b]));
+                HIP_TRY(hipMalloc(&s->d_blk[c][b], sizeof(double) * (size_t)m->NBLK * s->npad));
+            }
         s->ops[c] = m;
     }
     s->same_focal = same_focal != 0;
@@ -516,6 +593,9 @@ int ccalib_solver_set_start(ccalib_solver* s, const double* intr, const unsigned
     HIP_TRY(hipMemcpy(s->d_pose_cur, rt, sizeof(double) * 6 * s->nviews, hipMemcpyHostToDevice));
     s->started = true;
     s->have_cached = false;
+    s->spec_valid = false;
+    s->steps_since_jac = 0;
+    s->prev_rejected = false;
     return CCALIB_OK;
 }
 
@@ -590,7 +670,7 @@ int ccalib_solver_eval_error(ccalib_solver* s, double* err) {
     HIP_TRY(hipSetDevice(s->device));
     int rc;
     if ((rc = ensure_part(s, s->grid_red))) return rc;
-    if ((rc = stereo_compose(s, false))) return rc;
+    if ((rc = stereo_compose(s, false, s->cur))) return rc;
     for (int c = 0; c < s->ncams; c++) {
         CamParams cp = cam_params(s->intr[c], s->aspect[c]);
         if (s->aspect[c] != 0) cp.fx = cp.fy * s->aspect[c];
@@ -618,7 +698,7 @@ int ccalib_solver_fetch_blocks(ccalib_solver* s, double* V, double* W, double* g
     const ModelOps* m = s->ops[0];
     std::vector<double> h((size_t)m->NBLK * s->npad);
     HIP_TRY(hipStreamSynchronize(s->stream));
-    HIP_TRY(hipMemcpy(h.data(), s->d_blk[0], sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h.data(), s->d_blk[0][s->cur], sizeof(double) * h.size(), hipMemcpyDeviceToHost));
     const int ns = 18;
     for (int v = 0; v < s->nviews; v++) {
         int k = 0;
@@ -642,6 +722,7 @@ int ccalib_solver_reduce(ccalib_solver* s, double lambda, double* Ssum, double* 
         for (int k = 0; k < kc; k++)
             if (s->kcol_to_shared(k) == i) fidx.push_back(i);
     s->have_cached = false;
+    s->spec_valid = false;
     return be_reduce(s, lambda, fidx.data(), (int)fidx.size(), Ssum, bsum);
 }
 
@@ -667,9 +748,9 @@ int ccalib_solver_time_kernels(ccalib_solver* s, int reps, double ms[3]) {
             if (which == 0)
                 m->jac_shared(a, cp, s->grid_red, s->d_part, s->stream);
             else if (which == 1 && fused)
-                m->jac_fused(a, cp, s->d_pc, s->grid_fused, s->d_blk[0], s->d_part, s->stream);
+                m->jac_fused(a, cp, s->d_pc, s->grid_fused, s->d_blk[0][s->cur], s->d_part, s->stream);
             else if (which == 1)
-                m->jac_view(a, cp, s->grid_view, s->d_blk[0], s->npad, s->stream);
+                m->jac_view(a, cp, s->grid_view, s->d_blk[0][s->cur], s->npad, s->stream);
             else
                 launch_err(a, cp, s->rational[0], s->grid_red, s->d_part, s->stream);
         };
@@ -684,6 +765,7 @@ int ccalib_solver_time_kernels(ccalib_solver* s, int reps, double ms[3]) {
     }
     (void)hipEventDestroy(e0), (void)hipEventDestroy(e1);
     s->have_cached = false;
+    s->spec_valid = false;
     return CCALIB_OK;
 }
 

@@ -215,7 +215,10 @@ int ccalib_solver_time_kernels(ccalib_solver* s, int reps, double ms[3]);
  *             Ssum (nf x nf, symmetric) = sum_i W_i V_i'^-1 W_i^T,  bsum (nf) = sum_i W_i V_i'^-1 ge_i
  *   step_err  trial poses = committed poses - V'^-1 (ge - W^T dshared) for every view, then the
  *             residual pass at (shared_new, trial poses); returns sum |delta_e|^2,
- *             sum |committed pose|^2 and the new sum of squared residuals
+ *             sum |committed pose|^2 and the new sum of squared residuals.  lambda_next is the
+ *             damping the driver will announce to jac() if this trial point is accepted, so a backend
+ *             may already run that Jacobian pass here (it yields the residual sum too) and answer
+ *             the following jac() call, made at the same point, from what it kept
  *   commit    trial poses become the committed poses
  *   fixup     called before every pass with the current and previous shared vectors so that ties
  *             between parameters (fixed aspect ratio, same focal length) can be enforced; may be NULL
@@ -224,7 +227,7 @@ typedef struct {
     int ns; /* shared parameter count (18 mono, 42 stereo) */
     int (*jac)(void* user, const double* shared, double lambda_hint, double* U, double* gs, double* err);
     int (*reduce)(void* user, double lambda, const int* fidx, int nf, double* Ssum, double* bsum);
-    int (*step_err)(void* user, double lambda, const int* fidx, int nf, const double* dshared,
+    int (*step_err)(void* user, double lambda, double lambda_next, const int* fidx, int nf, const double* dshared,
                     const double* shared_new, double* dnorm2, double* pnorm2, double* err);
     int (*commit)(void* user);
     void (*fixup)(void* user, double* shared, double* prev_shared);

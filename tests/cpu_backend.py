@@ -73,7 +73,7 @@ class OracleBackend:
         np.ctypeslib.as_array(bsum, shape=(nf,))[:] = packed[nf * nf:]
         return 0
 
-    def _step_err(self, _u, lam, fidx, nf, dshared, shared_new, dn2, pn2, err):
+    def _step_err(self, _u, lam, _lam_next, fidx, nf, dshared, shared_new, dn2, pn2, err):
         self.calls["step_err"] += 1
         d = np.ctypeslib.as_array(dshared, shape=(nf,)).copy()
         sh = np.ctypeslib.as_array(shared_new, shape=(18,)).copy()

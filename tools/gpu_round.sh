@@ -2,6 +2,5 @@ set -e
 mkdir -p gpurun_out
 timeout -k 10 700 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/t.log 2>&1 || { tail -40 gpurun_out/t.log; exit 1; }
 tail -3 gpurun_out/t.log
-timeout -k 10 120 python tools/kernel_bench.py
-CCALIB_NO_FUSED=1 timeout -k 10 120 python tools/kernel_bench.py
-timeout -k 10 300 python bench.py --steps 20 --warmup 3 --no-cpu
+timeout -k 10 300 python bench.py --steps 20 --warmup 3 --no-cpu | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['rms_px'], d['jac_passes'], d['err_passes'], d['roofline']['launch_ms'])"
+CCALIB_NO_AHEAD=1 timeout -k 10 300 python bench.py --steps 20 --warmup 3 --no-cpu | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['rms_px'], d['jac_passes'], d['err_passes'], d['roofline']['launch_ms'])"
