@@ -349,16 +349,19 @@ __global__ __launch_bounds__(kBlock, CCALIB_VIEW_MINWAVES) void k_jac_view(PassA
 // RS mod 32 in {2, 14, 18, 30} so that the 16-byte reads of 16 columns fall in disjoint banks.
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
+__device__ __forceinline__ void store_pose_const(const double ps[6], double* o) {
+    PoseConst q = pose_const(ps);
+    o[0] = q.ax[0], o[1] = q.ax[1], o[2] = q.ax[2], o[3] = q.c, o[4] = q.c1, o[5] = q.s, o[6] = q.b1, o[7] = q.b2;
+    o[8] = q.b3, o[9] = q.b4, o[10] = q.t[0], o[11] = q.t[1], o[12] = q.t[2], o[13] = 0, o[14] = 0, o[15] = 0;
+}
+
 __global__ __launch_bounds__(64) void k_pose_const(const double* pose, int nviews, double* pc) {
     int v = blockIdx.x * 64 + threadIdx.x;
     if (v >= nviews) return;
     double ps[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) ps[k] = pose[6 * (size_t)v + k];
-    PoseConst q = pose_const(ps);
-    double* o = pc + kPoseConstStride * (size_t)v;
-    o[0] = q.ax[0], o[1] = q.ax[1], o[2] = q.ax[2], o[3] = q.c, o[4] = q.c1, o[5] = q.s, o[6] = q.b1, o[7] = q.b2;
-    o[8] = q.b3, o[9] = q.b4, o[10] = q.t[0], o[11] = q.t[1], o[12] = q.t[2], o[13] = 0, o[14] = 0, o[15] = 0;
+    store_pose_const(ps, pc + kPoseConstStride * (size_t)v);
 }
 
 template <class M, bool SHARED>
@@ -574,9 +577,10 @@ __global__ __launch_bounds__(64) void k_schur(const double* blk, int npad, int n
 }
 
 // trial pose = committed pose - V'^-1 (ge - W^T dc).  part per workgroup: sum |delta|^2, sum |pose_prev|^2.
+// With pc != null the trial pose is also written in the form the fused Jacobian kernel reads.
 template <int NC>
 __global__ __launch_bounds__(64) void k_backsub(const double* blk, int npad, int nviews, double lambda, DeltaC dc,
-                                                const double* pose_prev, double* pose_cur, double* part) {
+                                                const double* pose_prev, double* pose_cur, double* part, double* pc) {
     constexpr int NB = 27 + 6 * NC;
     int v = blockIdx.x * 64 + threadIdx.x;
     bool live = v < nviews;
@@ -595,15 +599,17 @@ __global__ __launch_bounds__(64) void k_backsub(const double* blk, int npad, int
     bool ok = chol6(Vu, lambda, L, invd);
     chol6_fwd(L, invd, rhs);
     chol6_bwd(L, invd, rhs);
-    double dn = 0, pn = 0;
+    double dn = 0, pn = 0, pnew[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) {
         double pv = pose_prev[6 * (size_t)vv + k];
         double d = ok ? rhs[k] : 0.;  // a singular view block gets no update
-        if (live) pose_cur[6 * (size_t)vv + k] = pv - d;
+        pnew[k] = pv - d;
+        if (live) pose_cur[6 * (size_t)vv + k] = pnew[k];
         dn += d * d;
         pn += pv * pv;
     }
+    if (pc && live) store_pose_const(pnew, pc + kPoseConstStride * (size_t)vv);
     dn = wave_sum(live ? dn : 0.);
     pn = wave_sum(live ? pn : 0.);
     if (threadIdx.x == 0) {
@@ -612,19 +618,44 @@ __global__ __launch_bounds__(64) void k_backsub(const double* blk, int npad, int
     }
 }
 
-// out[k] = sum over rows of part[row * n + k]; one workgroup per k, fixed-order tree.
-__global__ __launch_bounds__(kBlock) void k_colsum(const double* part, int nrows, int n, double* out) {
+// Column sums of several partial-result tables in one launch.  Workgroup b reduces one column of
+// one table: out[seg.out_ofs + k] = sum over rows of seg.part[row * seg.n + k], as a fixed-order tree.
+// `out` may be host memory the device can write; the last workgroup to finish then stores `seq` to
+// *flag (also host memory), which a polling host thread takes as "all sums have landed".
+__global__ __launch_bounds__(kBlock) void k_colsum(ColsumArgs a, double* out, unsigned* counter,
+                                                   volatile unsigned long long* flag, unsigned long long seq) {
     __shared__ double sm[kBlock];
-    int k = blockIdx.x;
+    int k = blockIdx.x, sidx = 0;
+    while (sidx + 1 < a.nseg && k >= a.seg[sidx].n) k -= a.seg[sidx].n, sidx++;
+    const ColsumSeg sg = a.seg[sidx];
     double s = 0;
-    for (int r = threadIdx.x; r < nrows; r += kBlock) s += part[(size_t)r * n + k];
+    for (int r = threadIdx.x; r < sg.nrows; r += kBlock) s += sg.part[(size_t)r * sg.n + k];
     sm[threadIdx.x] = s;
     __syncthreads();
     for (int h = kBlock / 2; h > 0; h >>= 1) {
         if ((int)threadIdx.x < h) sm[threadIdx.x] += sm[threadIdx.x + h];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[k] = sm[0];
+    if (threadIdx.x == 0) {
+        out[sg.out_ofs + k] = sm[0];
+        if (flag) {
+            __threadfence_system();
+            if (atomicAdd(counter, 1u) == gridDim.x - 1) {
+                *counter = 0;
+                __threadfence_system();
+                *flag = seq;
+            }
+        }
+    }
+}
+
+// Copies n doubles to host-visible memory and then raises the flag (used after an in-stream all-reduce).
+__global__ __launch_bounds__(kBlock) void k_publish(const double* src, int n, double* dst, volatile unsigned long long* flag,
+                                                    unsigned long long seq) {
+    for (int i = threadIdx.x; i < n; i += kBlock) dst[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) *flag = seq;
 }
 
 // ---- launchers -------------------------------------------------------------------------------
@@ -675,9 +706,9 @@ static void launch_schur(const double* blk, int npad, int nviews, double lambda,
 }
 template <int NC>
 static void launch_backsub(const double* blk, int npad, int nviews, double lambda, const DeltaC& dc,
-                           const double* pose_prev, double* pose_cur, double* part, hipStream_t st) {
+                           const double* pose_prev, double* pose_cur, double* part, double* pc, hipStream_t st) {
     hipLaunchKernelGGL(k_backsub<NC>, dim3((nviews + 63) / 64), dim3(64), 0, st, blk, npad, nviews, lambda, dc,
-                       pose_prev, pose_cur, part);
+                       pose_prev, pose_cur, part, pc);
 }
 
 template <class M>
@@ -741,8 +772,15 @@ void launch_reproj(const PassArgs& a, const CamParams& cp, bool rational, int gr
     });
 }
 
-void launch_colsum(const double* part, int nrows, int n, double* out, hipStream_t st) {
-    hipLaunchKernelGGL(k_colsum, dim3(n), dim3(kBlock), 0, st, part, nrows, n, out);
+void launch_colsum(const ColsumArgs& a, double* out, unsigned* counter, unsigned long long* flag, unsigned long long seq,
+                   hipStream_t st) {
+    int total = 0;
+    for (int i = 0; i < a.nseg; i++) total += a.seg[i].n;
+    if (total > 0) hipLaunchKernelGGL(k_colsum, dim3(total), dim3(kBlock), 0, st, a, out, counter, flag, seq);
+}
+
+void launch_publish(const double* src, int n, double* dst, unsigned long long* flag, unsigned long long seq, hipStream_t st) {
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(kBlock), 0, st, src, n, dst, flag, seq);
 }
 
 void launch_pose_const(const double* pose, int nviews, double* pc, hipStream_t st) {

@@ -53,7 +53,7 @@ struct ModelOps {
     void (*jac_view)(const PassArgs&, const CamParams&, int grid, double* blk, int npad, hipStream_t);
     void (*schur)(const double* blk, int npad, int nviews, double lambda, double* part, hipStream_t);
     void (*backsub)(const double* blk, int npad, int nviews, double lambda, const DeltaC&, const double* pose_prev,
-                    double* pose_cur, double* part, hipStream_t);
+                    double* pose_cur, double* part, double* pc, hipStream_t);
     // whole Jacobian pass in one kernel (shared block partials: 4 * grid rows of NRED_U); null when the
     // column set does not fit the 16-wide matrix tile
     void (*jac_fused)(const PassArgs&, const CamParams&, const double* pc, int grid, double* blk, double* part,
@@ -75,7 +75,19 @@ void launch_err(const PassArgs&, const CamParams&, bool rational, int grid, doub
 // projected pixels (as float, optional) and the squared reprojection error of every view
 void launch_reproj(const PassArgs&, const CamParams&, bool rational, int grid, float2* proj, double* view_err,
                    hipStream_t);
-void launch_colsum(const double* part, int nrows, int n, double* out, hipStream_t);
+// One launch reduces the partial-result tables of a whole pass (see k_colsum).
+struct ColsumSeg {
+    const double* part;
+    int nrows, n, out_ofs;
+};
+constexpr int kMaxColsumSegs = 8;
+struct ColsumArgs {
+    ColsumSeg seg[kMaxColsumSegs];
+    int nseg;
+};
+void launch_colsum(const ColsumArgs&, double* out, unsigned* counter, unsigned long long* flag, unsigned long long seq,
+                   hipStream_t);
+void launch_publish(const double* src, int n, double* dst, unsigned long long* flag, unsigned long long seq, hipStream_t);
 int pass_block_size();
 // dynamic LDS one workgroup of the per-point kernels needs
 size_t pass_lds_bytes(int G, int maxnp, bool shared_board, int board_np);

@@ -12,6 +12,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -61,10 +62,17 @@ struct ccalib_solver {
     double* d_cmp[2] = {nullptr, nullptr};                  // stereo: per-view composition Jacobians (SoA), per buffer
     double* d_blk[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [camera][buffer]
     double* d_pc = nullptr;  // nviews x kPoseConstStride: poses in the form the fused Jacobian kernel reads
+    bool pc_fresh = false;   // d_pc matches d_pose_cur
+    // Partial results of the kernels of one pass: a bump-allocated arena, reduced by ONE column-sum
+    // launch per pass whose output goes straight to pinned host memory; the host polls a flag there.
     double* d_part = nullptr;
-    size_t part_cap = 0;
+    size_t part_cap = 0, part_used = 0;
+    ColsumArgs segs;
     double* d_red = nullptr;
-    double* h_red = nullptr;  // pinned
+    double* h_red = nullptr;                 // pinned, device-writable
+    unsigned long long* h_flag = nullptr;    // pinned
+    unsigned* d_counter = nullptr;
+    unsigned long long seq = 0;
     static constexpr int kRedCap = 4096;
 
     // parameters
@@ -135,11 +143,51 @@ PassArgs pass_args(const ccalib_solver* s, int cam, const double* pose) {
     return a;
 }
 
-// Sums d_red[0..n) over ranks (if any) and brings it to h_red.
+// Arena for the partial results of the current pass.
+double* part_take(ccalib_solver* s, size_t n) {
+    n = (n + 31) / 32 * 32;
+    if (s->part_used + n > s->part_cap) return nullptr;
+    double* p = s->d_part + s->part_used;
+    s->part_used += n;
+    return p;
+}
+#define PART_TAKE(ptr, s, n)                                                                   \
+    double* ptr = part_take(s, n);                                                             \
+    if (!ptr) return set_error(CCALIB_ERR_STATE, "partial-result arena exhausted (%s:%d)", __FILE__, __LINE__)
+
+int queue_colsum(ccalib_solver* s, const double* part, int nrows, int n, int out_ofs) {
+    if (s->segs.nseg >= kMaxColsumSegs) return set_error(CCALIB_ERR_STATE, "too many reductions in one pass");
+    s->segs.seg[s->segs.nseg++] = ColsumSeg{part, nrows, n, out_ofs};
+    return CCALIB_OK;
+}
+
+// Reduces everything queued in this pass into n sums, over ranks too (if any), and waits for them
+// in h_red.  Single rank and callback runs: the column-sum kernel writes pinned host memory directly
+// and raises a flag the host polls (no copy, no interrupt).  RCCL runs: sums land in d_red, are
+// all-reduced in-stream and then published the same way.
 int finish_reduction(ccalib_solver* s, int n) {
-    if (s->comm) NCCL_TRY(ncclAllReduce(s->d_red, s->d_red, n, ncclDouble, ncclSum, s->comm, s->stream));
-    HIP_TRY(hipMemcpyAsync(s->h_red, s->d_red, sizeof(double) * n, hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    const unsigned long long seq = ++s->seq;
+    if (s->comm) {
+        launch_colsum(s->segs, s->d_red, s->d_counter, nullptr, 0, s->stream);
+        NCCL_TRY(ncclAllReduce(s->d_red, s->d_red, n, ncclDouble, ncclSum, s->comm, s->stream));
+        launch_publish(s->d_red, n, s->h_red, s->h_flag, seq, s->stream);
+    } else {
+        launch_colsum(s->segs, s->h_red, s->d_counter, s->h_flag, seq, s->stream);
+    }
+    s->segs.nseg = 0;
+    s->part_used = 0;
+    HIP_TRY(hipGetLastError());
+    volatile unsigned long long* flag = s->h_flag;
+    for (unsigned spins = 0; *flag != seq; spins++) {
+        if ((spins & 0xffff) == 0xffff) {  // a failed launch or a fault must not leave the host spinning
+            hipError_t q = hipStreamQuery(s->stream);
+            if (q != hipSuccess && q != hipErrorNotReady)
+                return set_error(CCALIB_ERR_HIP, "stream failed while waiting for a reduction: %s", hipGetErrorString(q));
+            if (q == hipSuccess && *flag != seq) return set_error(CCALIB_ERR_HIP, "reduction finished without publishing");
+        }
+        __builtin_ia32_pause();
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
     if (s->cb) {
         int rc = s->cb(s->cb_user, s->h_red, n);
         if (rc) return set_error(CCALIB_ERR_HIP, "all-reduce callback failed (%d)", rc);
@@ -147,12 +195,16 @@ int finish_reduction(ccalib_solver* s, int n) {
     return CCALIB_OK;
 }
 
-int ensure_part(ccalib_solver* s, size_t n) {
-    if (n <= s->part_cap) return CCALIB_OK;
-    if (s->d_part) HIP_TRY(hipFree(s->d_part));
-    HIP_TRY(hipMalloc(&s->d_part, sizeof(double) * n));
-    s->part_cap = n;
-    return CCALIB_OK;
+// Worst-case arena size of one pass (doubles).
+size_t part_capacity(const ccalib_solver* s) {
+    size_t n = 0;
+    int kc = s->kcols();
+    for (int c = 0; c < s->ncams; c++)
+        n += (size_t)std::max(s->grid_fused * kTileViews, s->grid_red) * s->ops[c]->NRED_U + 64 + (size_t)s->grid_red + 64;
+    n += (size_t)s->nblk64 * (kc * (kc + 1) / 2 + kc) + 64;  // Schur sums
+    n += (size_t)s->nblk64 * 2 + 64;                          // step norms
+    if (s->ncams == 2) n += (size_t)s->nblk64 * (27 + 6 * s->ops[1]->NC) + 64;
+    return n;
 }
 
 const double* cam_pose(const ccalib_solver* s, int cam) { return cam == 0 ? s->d_pose_cur : s->d_pose3; }
@@ -192,15 +244,13 @@ int stereo_compose(ccalib_solver* s, bool with_jac, int buf) {
 // at `ofs`.  Layout appended: upper triangle (kc(kc+1)/2) then right-hand side (kc), kc = kernel columns.
 int enqueue_schur(ccalib_solver* s, int buf, double lambda, int ofs) {
     int kc = s->kcols(), nsum = kc * (kc + 1) / 2 + kc;
-    int rc = ensure_part(s, (size_t)s->nblk64 * nsum);
-    if (rc) return rc;
+    PART_TAKE(part, s, (size_t)s->nblk64 * nsum);
     if (s->ncams == 1)
-        s->ops[0]->schur(s->d_blk[0][buf], s->npad, s->nviews, lambda, s->d_part, s->stream);
+        s->ops[0]->schur(s->d_blk[0][buf], s->npad, s->nviews, lambda, part, s->stream);
     else if (!launch_stereo_schur(s->ops[0]->NC, s->d_blk[0][buf], s->d_blk[1][buf], s->d_cmp[buf], s->lr_jac[buf],
-                                  s->npad, s->nviews, lambda, s->d_part, s->stream))
+                                  s->npad, s->nviews, lambda, part, s->stream))
         return set_error(CCALIB_ERR_UNSUPPORTED, "stereo column count %d is not built in", s->ops[0]->NC);
-    launch_colsum(s->d_part, s->nblk64, nsum, s->d_red + ofs, s->stream);
-    return CCALIB_OK;
+    return queue_colsum(s, part, s->nblk64, nsum, ofs);
 }
 
 // Where the sums of one Jacobian pass sit in d_red / h_red.
@@ -221,14 +271,15 @@ int enqueue_jac(ccalib_solver* s, int buf, double lambda_hint, int ofs, JacLayou
         PassArgs a = pass_args(s, c, cam_pose(s, c));
         if (m->jac_fused && s->use_fused) {
             int rows = s->grid_fused * kTileViews;
-            if ((rc = ensure_part(s, (size_t)rows * m->NRED_U))) return rc;
-            launch_pose_const(a.pose, s->nviews, s->d_pc, s->stream);
-            m->jac_fused(a, cp, s->d_pc, s->grid_fused, s->d_blk[c][buf], s->d_part, s->stream);
-            launch_colsum(s->d_part, rows, m->NRED_U, s->d_red + ofs, s->stream);
+            PART_TAKE(part, s, (size_t)rows * m->NRED_U);
+            if (!s->pc_fresh) launch_pose_const(a.pose, s->nviews, s->d_pc, s->stream);
+            s->pc_fresh = s->ncams == 1;  // one record array: with two cameras each pass rewrites it
+            m->jac_fused(a, cp, s->d_pc, s->grid_fused, s->d_blk[c][buf], part, s->stream);
+            if ((rc = queue_colsum(s, part, rows, m->NRED_U, ofs))) return rc;
         } else {
-            if ((rc = ensure_part(s, (size_t)s->grid_red * m->NRED_U))) return rc;
-            m->jac_shared(a, cp, s->grid_red, s->d_part, s->stream);
-            launch_colsum(s->d_part, s->grid_red, m->NRED_U, s->d_red + ofs, s->stream);
+            PART_TAKE(part, s, (size_t)s->grid_red * m->NRED_U);
+            m->jac_shared(a, cp, s->grid_red, part, s->stream);
+            if ((rc = queue_colsum(s, part, s->grid_red, m->NRED_U, ofs))) return rc;
             m->jac_view(a, cp, s->grid_view, s->d_blk[c][buf], s->npad, s->stream);
         }
         L.cam_ofs[c] = ofs;
@@ -238,11 +289,11 @@ int enqueue_jac(ccalib_solver* s, int buf, double lambda_hint, int ofs, JacLayou
     if (s->ncams == 2) {
         // shared-block pieces that involve the relative pose: B^T V3 B (21), B^T ge3 (6), W3 B (NC1 x 6)
         int n = 27 + 6 * s->ops[1]->NC;
-        if ((rc = ensure_part(s, (size_t)s->nblk64 * n))) return rc;
+        PART_TAKE(part, s, (size_t)s->nblk64 * n);
         if (!launch_stereo_lr_sums(s->ops[1]->NC, s->d_blk[1][buf], s->d_cmp[buf], s->lr_jac[buf], s->npad, s->nviews,
-                                   s->d_part, s->stream))
+                                   part, s->stream))
             return set_error(CCALIB_ERR_UNSUPPORTED, "stereo column count %d is not built in", s->ops[1]->NC);
-        launch_colsum(s->d_part, s->nblk64, n, s->d_red + ofs, s->stream);
+        if ((rc = queue_colsum(s, part, s->nblk64, n, ofs))) return rc;
         ofs += n;
     }
     L.schur_ofs = ofs;
@@ -357,22 +408,24 @@ int be_step_err(void* user, double lambda, double lambda_next, const int* fidx, 
     const int cur = s->cur;
     std::vector<double> dfull(s->ns(), 0.);
     for (int a = 0; a < nf; a++) dfull[fidx[a]] = dshared[a];
-    if ((rc = ensure_part(s, (size_t)std::max(s->nblk64 * 2, s->grid_red)))) return rc;
+    PART_TAKE(npart, s, (size_t)s->nblk64 * 2);
     if (s->ncams == 1) {
         DeltaC dc;
         for (int k = 0; k < I_NMODEL; k++) dc.v[k] = 0;
         for (int k = 0; k < s->ops[0]->NC; k++) dc.v[k] = dfull[s->ops[0]->col(k)];
-        s->ops[0]->backsub(s->d_blk[0][cur], s->npad, s->nviews, lambda, dc, s->d_pose_prev, s->d_pose_cur, s->d_part,
-                           s->stream);
+        const bool want_pc = s->ops[0]->jac_fused && s->use_fused;
+        s->ops[0]->backsub(s->d_blk[0][cur], s->npad, s->nviews, lambda, dc, s->d_pose_prev, s->d_pose_cur, npart,
+                           want_pc ? s->d_pc : nullptr, s->stream);
+        s->pc_fresh = want_pc;
     } else {
         StereoDelta sd;
         int kc = s->kcols();
         for (int k = 0; k < kStereoMaxCols; k++) sd.v[k] = k < kc ? dfull[s->kcol_to_shared(k)] : 0.;
         if (!launch_stereo_backsub(s->ops[0]->NC, s->d_blk[0][cur], s->d_blk[1][cur], s->d_cmp[cur], s->lr_jac[cur],
-                                   s->npad, s->nviews, lambda, sd, s->d_pose_prev, s->d_pose_cur, s->d_part, s->stream))
+                                   s->npad, s->nviews, lambda, sd, s->d_pose_prev, s->d_pose_cur, npart, s->stream))
             return set_error(CCALIB_ERR_UNSUPPORTED, "stereo column count %d is not built in", s->ops[0]->NC);
     }
-    launch_colsum(s->d_part, s->nblk64, 2, s->d_red, s->stream);
+    if ((rc = queue_colsum(s, npart, s->nblk64, 2, 0))) return rc;
     store_shared(s, shared_new);
     const bool ahead = s->speculate && s->steps_since_jac == 0 && !s->prev_rejected;
     s->steps_since_jac++;
@@ -396,8 +449,9 @@ int be_step_err(void* user, double lambda, double lambda_next, const int* fidx, 
         for (int c = 0; c < s->ncams; c++) {
             CamParams cp = cam_params(s->intr[c], s->aspect[c]);
             PassArgs a = pass_args(s, c, cam_pose(s, c));
-            launch_err(a, cp, s->rational[c], s->grid_red, s->d_part, s->stream);
-            launch_colsum(s->d_part, s->grid_red, 1, s->d_red + 2 + c, s->stream);
+            PART_TAKE(epart, s, (size_t)s->grid_red);
+            launch_err(a, cp, s->rational[c], s->grid_red, epart, s->stream);
+            if ((rc = queue_colsum(s, epart, s->grid_red, 1, 2 + c))) return rc;
         }
         if ((rc = finish_reduction(s, 2 + s->ncams))) return rc;
         *err = s->h_red[2] + (s->ncams == 2 ? s->h_red[3] : 0.);
@@ -537,6 +591,11 @@ int ccalib_solver_create(ccalib_solver** out, int device, int ncams, int nviews,
     }
     HIP_TRY(hipMalloc(&s->d_red, sizeof(double) * ccalib_solver::kRedCap));
     HIP_TRY(hipHostMalloc(&s->h_red, sizeof(double) * ccalib_solver::kRedCap));
+    HIP_TRY(hipHostMalloc(&s->h_flag, sizeof(unsigned long long)));
+    *s->h_flag = 0;
+    HIP_TRY(hipMalloc(&s->d_counter, sizeof(unsigned)));
+    HIP_TRY(hipMemset(s->d_counter, 0, sizeof(unsigned)));
+    s->segs.nseg = 0;
     *out = s;
     return CCALIB_OK;
 }
@@ -551,6 +610,8 @@ void ccalib_solver_destroy(ccalib_solver* s) {
     for (int b = 0; b < 2; b++) (void)hipFree(s->d_cmp[b]), (void)hipFree(s->d_blk[0][b]), (void)hipFree(s->d_blk[1][b]);
     (void)hipFree(s->d_pc), (void)hipFree(s->d_part), (void)hipFree(s->d_red);
     if (s->h_red) (void)hipHostFree(s->h_red);
+    if (s->h_flag) (void)hipHostFree(s->h_flag);
+    (void)hipFree(s->d_counter);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -588,10 +649,21 @@ int ccalib_solver_set_start(ccalib_solver* s, const double* intr, const unsigned
             }
         s->ops[c] = m;
     }
+    {
+        size_t need = part_capacity(s);
+        if (need > s->part_cap) {
+            if (s->d_part) HIP_TRY(hipFree(s->d_part));
+            HIP_TRY(hipMalloc(&s->d_part, sizeof(double) * need));
+            s->part_cap = need;
+        }
+        s->part_used = 0;
+        s->segs.nseg = 0;
+    }
     s->same_focal = same_focal != 0;
     if (lr) std::memcpy(s->lr, lr, sizeof(double) * 6);
     HIP_TRY(hipMemcpy(s->d_pose_cur, rt, sizeof(double) * 6 * s->nviews, hipMemcpyHostToDevice));
     s->started = true;
+    s->pc_fresh = false;
     s->have_cached = false;
     s->spec_valid = false;
     s->steps_since_jac = 0;
@@ -669,14 +741,14 @@ int ccalib_solver_eval_error(ccalib_solver* s, double* err) {
     if (!s || !s->started || !err) return set_error(CCALIB_ERR_STATE, "eval_error before set_start");
     HIP_TRY(hipSetDevice(s->device));
     int rc;
-    if ((rc = ensure_part(s, s->grid_red))) return rc;
     if ((rc = stereo_compose(s, false, s->cur))) return rc;
     for (int c = 0; c < s->ncams; c++) {
         CamParams cp = cam_params(s->intr[c], s->aspect[c]);
         if (s->aspect[c] != 0) cp.fx = cp.fy * s->aspect[c];
         PassArgs a = pass_args(s, c, cam_pose(s, c));
-        launch_err(a, cp, s->rational[c], s->grid_red, s->d_part, s->stream);
-        launch_colsum(s->d_part, s->grid_red, 1, s->d_red + c, s->stream);
+        PART_TAKE(epart, s, (size_t)s->grid_red);
+        launch_err(a, cp, s->rational[c], s->grid_red, epart, s->stream);
+        if ((rc = queue_colsum(s, epart, s->grid_red, 1, c))) return rc;
     }
     if ((rc = finish_reduction(s, s->ncams))) return rc;
     *err = s->h_red[0] + (s->ncams == 2 ? s->h_red[1] : 0.);
@@ -734,11 +806,12 @@ int ccalib_solver_time_kernels(ccalib_solver* s, int reps, double ms[3]) {
     HIP_TRY(hipEventCreate(&e1));
     const ModelOps* m = s->ops[0];
     const bool fused = m->jac_fused && s->use_fused;
-    int rc = ensure_part(s, (size_t)std::max(s->grid_red, s->grid_fused * kTileViews) * m->NRED_U);
-    if (rc) return rc;
+    s->part_used = 0;
+    PART_TAKE(tpart, s, (size_t)std::max(s->grid_red, s->grid_fused * kTileViews) * m->NRED_U);
+    s->part_used = 0;
     CamParams cp = cam_params(s->intr[0], s->aspect[0]);
     PassArgs a = pass_args(s, 0, s->d_pose_cur);
-    if (fused) launch_pose_const(a.pose, s->nviews, s->d_pc, s->stream);
+    if (fused) launch_pose_const(a.pose, s->nviews, s->d_pc, s->stream), s->pc_fresh = true;
     for (int which = 0; which < 3; which++) {
         if (which == 0 && fused) {  // the fused kernel does the shared block as well
             ms[0] = 0.;
@@ -746,13 +819,13 @@ int ccalib_solver_time_kernels(ccalib_solver* s, int reps, double ms[3]) {
         }
         auto launch = [&]() {
             if (which == 0)
-                m->jac_shared(a, cp, s->grid_red, s->d_part, s->stream);
+                m->jac_shared(a, cp, s->grid_red, tpart, s->stream);
             else if (which == 1 && fused)
-                m->jac_fused(a, cp, s->d_pc, s->grid_fused, s->d_blk[0][s->cur], s->d_part, s->stream);
+                m->jac_fused(a, cp, s->d_pc, s->grid_fused, s->d_blk[0][s->cur], tpart, s->stream);
             else if (which == 1)
                 m->jac_view(a, cp, s->grid_view, s->d_blk[0][s->cur], s->npad, s->stream);
             else
-                launch_err(a, cp, s->rational[0], s->grid_red, s->d_part, s->stream);
+                launch_err(a, cp, s->rational[0], s->grid_red, tpart, s->stream);
         };
         launch();  // warm-up
         HIP_TRY(hipEventRecord(e0, s->stream));
