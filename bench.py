@@ -31,12 +31,17 @@ import __graft_entry__ as ge  # noqa: E402
 
 # Algorithmic FP64 flops per point (FMA = 2), instrumented by oracle/flopcount.py on the
 # zero-exploiting, factored formulation; and algorithmic HBM bytes per point for P = 54, c = 9.
-FLOPS_JAC_VIEW = 428       # per-view-block kernel (dominant): projection + Jacobians + V, ge, W updates
-FLOPS_JAC_PASS = 556       # whole Jacobian pass if done in one sweep
+FLOPS_JAC_PASS = 556       # whole Jacobian pass in one sweep: projection + Jacobians + U, gc, V, ge, W updates
+FLOPS_JAC_VIEW = 428       # the per-view-block part alone (the two-kernel path for rational models)
 FLOPS_RESIDUAL = 54
-BYTES_JAC_VIEW = (8 * 54 + 48 + 8 * (21 + 6 + 6 * 9)) / 54.0   # image points + pose in, blocks out, per point
-PEAK_FP64_VALU_TFLOPS = 78.6   # MI355X FP64 vector peak (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
+# The fused kernel does not exploit the zeros: it multiplies the dense 16-column row matrix on the
+# FP64 matrix pipe (ceil(2P/16)*4 instructions of 16x16x4 per view) after ~156 vector FP64
+# instructions per point.  Executed flops are reported beside the algorithmic ones.
+MFMA_FLOPS = 2 * 16 * 16 * 4
+BYTES_JAC_VIEW = (8 * 54 + 104 + 8 * (21 + 6 + 6 * 9)) / 54.0   # image points + pose record in, blocks out, per point
+PEAK_FP64_TFLOPS = 78.6    # MI355X dense FP64, matrix and vector alike (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
 PEAK_HBM_GBPS = 8000.0
+PROFILE_PMC = os.path.join(ROOT, "profiles", "r01_bench_hbm_pmc_v3.json")   # rocprofv3 FETCH_SIZE / WRITE_SIZE passes
 
 
 def parse():
@@ -135,20 +140,36 @@ def main():
     if rank == 0:
         # dominant kernel alone, HIP events on the solver's stream
         solver.set_start(out["intr"], mask, out["rt"])
-        km = solver.time_kernels(reps=20)
-        t_view = km["jac_view"] * 1e-3
-        achieved_tf = FLOPS_JAC_VIEW * points_local / t_view / 1e12
+        km = solver.time_kernels(reps=50)
+        fused = km["jac_shared"] == 0.0      # the fused kernel covers the whole Jacobian pass
+        t_jac = km["jac_view"] * 1e-3
+        flops_alg = FLOPS_JAC_PASS if fused else FLOPS_JAC_VIEW
+        achieved_tf = flops_alg * points_local / t_jac / 1e12
+        P = int(obj.shape[0])
+        executed = (-(-2 * P // 16) * 4 * MFMA_FLOPS + 2 * 156 * P) / P if fused else None
+        traffic = None
+        try:   # per-launch HBM bytes from the committed counter passes (FETCH_SIZE doubled, as gfx950 needs)
+            pm = json.load(open(PROFILE_PMC))
+            for name, c in pm.items():
+                if name.startswith("k_jac_fused" if fused else "k_jac_view"):
+                    traffic = int((2 * c["FETCH_SIZE"]["mean_per_launch"] + c["WRITE_SIZE"]["mean_per_launch"]) * 1024)
+        except (OSError, KeyError, ValueError):
+            pass
         roofline = {
-            "bound": "fp64_valu", "kernel": "k_jac_view", "achieved": round(achieved_tf, 3),
-            "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved_tf / PEAK_FP64_VALU_TFLOPS, 4),
-            "traffic": None,
+            "bound": "mfma", "kernel": "k_jac_fused" if fused else "k_jac_view", "achieved": round(achieved_tf, 3),
+            "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved_tf / PEAK_FP64_TFLOPS, 4),
+            "traffic": traffic,
             "launch_ms": round(km["jac_view"], 4),
-            "hbm_achieved_GBps": round(BYTES_JAC_VIEW * points_local / t_view / 1e9, 1),
-            "hbm_frac": round(BYTES_JAC_VIEW * points_local / t_view / 1e9 / PEAK_HBM_GBPS, 4),
+            "algorithmic_flops_per_point": flops_alg,
+            "executed_flops_per_point": round(executed, 1) if executed else None,
+            "executed_tflops": round(executed * points_local / t_jac / 1e12, 2) if executed else None,
+            "algorithmic_bytes_per_launch": int(BYTES_JAC_VIEW * points_local),
+            "hbm_achieved_GBps": round(BYTES_JAC_VIEW * points_local / t_jac / 1e9, 1),
+            "hbm_frac": round(BYTES_JAC_VIEW * points_local / t_jac / 1e9 / PEAK_HBM_GBPS, 4),
             "other_kernels_ms": {"k_jac_shared": round(km["jac_shared"], 4), "k_err": round(km["err"], 4)},
-            "jacobian_pass_frac": round(FLOPS_JAC_PASS * points_local / ((km["jac_view"] + km["jac_shared"]) * 1e-3)
-                                        / 1e12 / PEAK_FP64_VALU_TFLOPS, 4),
-            "note": "no MFMA on this path; bound is the FP64 vector ALU (flops instrumented by oracle/flopcount.py)",
+            "note": "FP64 path: the normal-equation update of a view is one A^T A product on the FP64 matrix pipe "
+                    "(v_mfma_f64_16x16x4), whose dense peak equals the FP64 vector peak on this part; achieved counts "
+                    "the zero-exploiting algorithmic flops (oracle/flopcount.py), executed_* what the kernel issues",
         }
         cpu = None
         if not args.no_cpu:

@@ -48,6 +48,13 @@ struct Model {
             }
         return -1;
     }
+    // position of intrinsic q among the produced columns, -1 when it is not produced
+    static constexpr int index_of(int q) {
+        if (!(MASK >> q & 1u)) return -1;
+        int seen = 0;
+        for (int p = 0; p < q; p++) seen += (int)(MASK >> p & 1u);
+        return seen;
+    }
     // does the column touch the u (x) / v (y) residual row, and is its entry the constant 1?
     static constexpr bool hasx(int i) {
         int q = col(i);

@@ -365,7 +365,7 @@ __global__ __launch_bounds__(64) void k_pose_const(const double* pose, int nview
 }
 
 template <class M, bool SHARED>
-__global__ __launch_bounds__(kBlock, 2) void k_jac_fused(PassArgs a, CamParams cp, const int* __restrict__ off,
+__global__ __launch_bounds__(kBlock, 3) void k_jac_fused(PassArgs a, CamParams cp, const int* __restrict__ off,
                                                          const double* __restrict__ pc, double* __restrict__ blk,
                                                          double* __restrict__ part, int RS, int CH, int dbg) {
     constexpr int NC = M::NC, NB = M::NBLK, NU = M::NU, NR = M::NRED_U;
@@ -374,11 +374,28 @@ __global__ __launch_bounds__(kBlock, 2) void k_jac_fused(PassArgs a, CamParams c
     static_assert(kWaves == kTileViews, "one wavefront per view of a tile");
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     stage_board(a);
+    // The principal-point columns are the same for every view -- (1, 0) and (0, 1) down the rows -- so
+    // when the set has both they are kept once per workgroup instead of once per wavefront; with 14
+    // instead of 16 private columns three workgroups fit a CU.  Their rows never read as zero past
+    // a view's last point, which only spoils the two sums of ones U(cx,cx), U(cy,cy): those are
+    // replaced by the exact point count when the wavefront stores its shared-block sums.
+    constexpr int ICX = M::index_of(I_CX), ICY = M::index_of(I_CY);
+    constexpr bool CONSTC = ICX >= 0 && ICY == ICX + 1;
+    constexpr int NPRIV = CONSTC ? 14 : 16;  // private columns per wavefront
     const int board_f = SHARED ? (3 * a.board_np + 3) / 4 * 4 : 0;  // floats, 16-byte granules
     double* const ldsd = reinterpret_cast<double*>(lds_dyn);  // indexed, so every access stays an LDS access
-    const int jt = board_f / 2 + w * 16 * RS;                 // this wavefront's buffer (in doubles)
+    const int cbase = board_f / 2;                             // the two shared columns (in doubles)
+    const int jt = cbase + (CONSTC ? 2 * RS : 0) + w * NPRIV * RS;  // this wavefront's buffer
+    auto slot = [&](int c) { return CONSTC && c > ICY ? c - 2 : c; };  // private column -> position in the buffer
+    if constexpr (CONSTC) {
+        for (int r = threadIdx.x; r < RS; r += kBlock) {
+            ldsd[cbase + r] = (r & 1) ? 0. : 1.;
+            ldsd[cbase + RS + r] = (r & 1) ? 1. : 0.;
+        }
+    }
     for (int c = NCOL; c < 16; c++)  // columns the set does not use stay zero
-        for (int r = lane; r < RS; r += 64) ldsd[jt + c * RS + r] = 0.;
+        for (int r = lane; r < RS; r += 64) ldsd[jt + slot(c) * RS + r] = 0.;
+    __syncthreads();
     // which results this lane's four accumulator registers hold: D[row][col], col = lane & 15,
     // row = (lane >> 4) + 4 * reg
     const int col = lane & 15, rq = lane >> 4;
@@ -443,11 +460,14 @@ __global__ __launch_bounds__(kBlock, 2) void k_jac_fused(PassArgs a, CamParams c
     }
     const double2* const lds2r = reinterpret_cast<const double2*>(lds_dyn);
     double2* const lds2 = reinterpret_cast<double2*>(lds_dyn);
-    const int src = ((jt + col * RS) >> 1) + rq;
+    const int colbase = CONSTC && col == ICX ? cbase : CONSTC && col == ICY ? cbase + RS : jt + slot(col) * RS;
+    const int src = (colbase >> 1) + rq;
     const int dst = (jt >> 1) + lane;  // in double2 units; RS is even
     int dirty = CH;                    // rows of points [n, dirty) hold an earlier view's values
+    int npsum = 0;                     // points this wavefront has seen
     while (valid) {
         const int n = np;              // the launcher guarantees np <= CH <= 64
+        npsum += n;
         const int tile_cur = tile;
         if (lane < n && !(dbg & 1)) {
             double qd[13];
@@ -467,16 +487,19 @@ __global__ __launch_bounds__(kBlock, 2) void k_jac_fused(PassArgs a, CamParams c
             PointOut<M> o;
             double jex[6], jey[6];
             point_jacobian<M>(q, cp, (double)X, (double)Y, (double)Z, (double)mpt.x, (double)mpt.y, o, jex, jey);
+            static_for<0, NC>([&](auto ic_) {
+                constexpr int i = decltype(ic_)::value;
+                if constexpr (!(CONSTC && (i == ICX || i == ICY)))
+                    lds2[dst + ((slot(i) * RS) >> 1)] = make_double2(o.jx[i], o.jy[i]);
+            });
 #pragma unroll
-            for (int i = 0; i < NC; i++) lds2[dst + ((i * RS) >> 1)] = make_double2(o.jx[i], o.jy[i]);
-#pragma unroll
-            for (int b = 0; b < 6; b++) lds2[dst + (((CPOSE + b) * RS) >> 1)] = make_double2(jex[b], jey[b]);
-            lds2[dst + ((CRES * RS) >> 1)] = make_double2(o.ex, o.ey);
+            for (int b = 0; b < 6; b++) lds2[dst + ((slot(CPOSE + b) * RS) >> 1)] = make_double2(jex[b], jey[b]);
+            lds2[dst + ((slot(CRES) * RS) >> 1)] = make_double2(o.ex, o.ey);
         }
         if (n < dirty) {  // rows past this view's last point must read as zero (wave-uniform branch)
             if (lane >= n && lane < dirty) {
 #pragma unroll
-                for (int c = 0; c < NCOL; c++) lds2[dst + ((c * RS) >> 1)] = make_double2(0., 0.);
+                for (int c = 0; c < NCOL - (CONSTC ? 2 : 0); c++) lds2[dst + ((c * RS) >> 1)] = make_double2(0., 0.);
             }
         }
         dirty = n;
@@ -526,8 +549,11 @@ __global__ __launch_bounds__(kBlock, 2) void k_jac_fused(PassArgs a, CamParams c
     }
     double* po = part + (size_t)(blockIdx.x * kWaves + w) * NR;
 #pragma unroll
-    for (int r = 0; r < 4; r++)
-        if (qu[r] >= 0) po[qu[r]] = usum[r];
+    for (int r = 0; r < 4; r++) {
+        const int row = rq + 4 * r;
+        const bool ones = CONSTC && row == col && (col == ICX || col == ICY);  // a sum of ones: the point count
+        if (qu[r] >= 0) po[qu[r]] = ones ? (double)npsum : usum[r];
+    }
 }
 
 // ---- per-view elimination --------------------------------------------------------------------
@@ -692,7 +718,8 @@ static void launch_jac_view(const PassArgs& a, const CamParams& cp, int grid, do
 template <class M>
 static void launch_jac_fused(const PassArgs& a, const CamParams& cp, const double* pc, int grid, double* blk, double* part,
                              hipStream_t st) {
-    FusedGeom g = fused_geom(a.maxnp, a.shared_board != 0, a.board_np);
+    constexpr bool const_cols = M::index_of(I_CX) >= 0 && M::index_of(I_CY) == M::index_of(I_CX) + 1;
+    FusedGeom g = fused_geom(a.maxnp, a.shared_board != 0, a.board_np, const_cols);
     int dbg = 0;
     if (const char* e = std::getenv("CCALIB_FUSED_DBG")) dbg = std::atoi(e);
     if (a.shared_board)
@@ -787,13 +814,14 @@ void launch_pose_const(const double* pose, int nviews, double* pc, hipStream_t s
     hipLaunchKernelGGL(k_pose_const, dim3((nviews + 63) / 64), dim3(64), 0, st, pose, nviews, pc);
 }
 
-FusedGeom fused_geom(int maxnp, bool shared_board, int board_np) {
+FusedGeom fused_geom(int maxnp, bool shared_board, int board_np, bool const_cols) {
     FusedGeom g;
     g.CH = maxnp >= 64 ? 64 : (maxnp + 7) / 8 * 8;
     g.RS = 2 * g.CH;
     while (!(g.RS % 32 == 2 || g.RS % 32 == 14 || g.RS % 32 == 18 || g.RS % 32 == 30)) g.RS += 2;
     size_t board_f = shared_board ? (size_t)(3 * board_np + 3) / 4 * 4 : 0;
-    g.lds_bytes = (unsigned)(sizeof(float) * board_f + sizeof(double) * kWaves * 16 * (size_t)g.RS);
+    // 14 private columns per wavefront + 2 shared ones when the principal point is in the set, else 16
+    g.lds_bytes = (unsigned)(sizeof(float) * board_f + sizeof(double) * (const_cols ? kWaves * 14 + 2 : kWaves * 16) * (size_t)g.RS);
     if (const char* e = std::getenv("CCALIB_LDS_PAD")) g.lds_bytes = std::max<unsigned>(g.lds_bytes, std::atoi(e));
     return g;
 }

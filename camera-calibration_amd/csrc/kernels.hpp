@@ -39,7 +39,7 @@ struct FusedGeom {
     int CH, RS;
     unsigned lds_bytes;
 };
-FusedGeom fused_geom(int maxnp, bool shared_board, int board_np);
+FusedGeom fused_geom(int maxnp, bool shared_board, int board_np, bool const_cols = true);
 
 struct DeltaC {
     double v[I_NMODEL];  // step of the kernel's intrinsic columns (0 for columns not optimised)

@@ -13,7 +13,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -73,6 +75,8 @@ struct ccalib_solver {
     unsigned long long* h_flag = nullptr;    // pinned
     unsigned* d_counter = nullptr;
     unsigned long long seq = 0;
+    double t_wait = 0, t_enqueue = 0;  // host seconds spent polling / inside backend calls before polling
+    std::chrono::steady_clock::time_point t_enter;
     static constexpr int kRedCap = 4096;
 
     // parameters
@@ -177,6 +181,8 @@ int finish_reduction(ccalib_solver* s, int n) {
     s->segs.nseg = 0;
     s->part_used = 0;
     HIP_TRY(hipGetLastError());
+    auto tw0 = std::chrono::steady_clock::now();
+    s->t_enqueue += std::chrono::duration<double>(tw0 - s->t_enter).count();
     volatile unsigned long long* flag = s->h_flag;
     for (unsigned spins = 0; *flag != seq; spins++) {
         if ((spins & 0xffff) == 0xffff) {  // a failed launch or a fault must not leave the host spinning
@@ -188,6 +194,7 @@ int finish_reduction(ccalib_solver* s, int n) {
         __builtin_ia32_pause();
     }
     std::atomic_thread_fence(std::memory_order_acquire);
+    s->t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count();
     if (s->cb) {
         int rc = s->cb(s->cb_user, s->h_red, n);
         if (rc) return set_error(CCALIB_ERR_HIP, "all-reduce callback failed (%d)", rc);
@@ -339,6 +346,7 @@ void parse_jac(const ccalib_solver* s, const JacLayout& L, double* U, double* gs
 
 int be_jac(void* user, const double* shared, double lambda_hint, double* U, double* gs, double* err) {
     ccalib_solver* s = (ccalib_solver*)user;
+    s->t_enter = std::chrono::steady_clock::now();
     const int ns = s->ns();
     s->prev_rejected = s->steps_since_jac > 1;
     s->steps_since_jac = 0;
@@ -371,6 +379,7 @@ int be_jac(void* user, const double* shared, double lambda_hint, double* U, doub
 
 int be_reduce(void* user, double lambda, const int* fidx, int nf, double* Ssum, double* bsum) {
     ccalib_solver* s = (ccalib_solver*)user;
+    s->t_enter = std::chrono::steady_clock::now();
     int kc = s->kcols(), nsum = kc * (kc + 1) / 2 + kc;
     if (!(s->have_cached && s->cached_lambda == lambda)) {
         int rc = enqueue_schur(s, s->cur, lambda, 0);
@@ -404,6 +413,7 @@ int be_reduce(void* user, double lambda, const int* fidx, int nf, double* Ssum, 
 int be_step_err(void* user, double lambda, double lambda_next, const int* fidx, int nf, const double* dshared,
                 const double* shared_new, double* dnorm2, double* pnorm2, double* err) {
     ccalib_solver* s = (ccalib_solver*)user;
+    s->t_enter = std::chrono::steady_clock::now();
     int rc;
     const int cur = s->cur;
     std::vector<double> dfull(s->ns(), 0.);
@@ -561,7 +571,7 @@ int ccalib_solver_create(ccalib_solver** out, int device, int ncams, int nviews,
     s->grid_view = (nviews + views_per_block - 1) / views_per_block;
     s->grid_red = std::min(s->grid_view, 512);
     if (const char* e = std::getenv("CCALIB_GRID_RED")) s->grid_red = std::max(1, std::min(s->grid_view, std::atoi(e)));
-    s->grid_fused = std::min((nviews + kTileViews - 1) / kTileViews, 512);  // two workgroups per CU
+    s->grid_fused = std::min((nviews + kTileViews - 1) / kTileViews, 768);  // three workgroups per CU
     if (const char* e = std::getenv("CCALIB_GRID_FUSED"))
         s->grid_fused = std::max(1, std::min((nviews + kTileViews - 1) / kTileViews, std::atoi(e)));
     if (const char* e = std::getenv("CCALIB_NO_FUSED")) s->use_fused = std::atoi(e) == 0;
@@ -712,8 +722,12 @@ int ccalib_solver_run(ccalib_solver* s, int term_type, int max_iter, double eps,
         std::memcpy(smask + 6, s->imask[0], 18);
         std::memcpy(smask + 24, s->imask[1], 18);
     }
+    s->t_wait = s->t_enqueue = 0;
     int rc = ccalib_lm_run(&be, s, shared, smask, term_type, max_iter, eps, solve_method, stats);
     store_shared(s, shared);
+    if (std::getenv("CCALIB_TIMING") && stats)
+        std::fprintf(stderr, "[ccalib] run: total %.3f ms, enqueue %.3f ms, polling %.3f ms, other host %.3f ms\n", stats->device_ms,
+                     s->t_enqueue * 1e3, s->t_wait * 1e3, stats->device_ms - (s->t_enqueue + s->t_wait) * 1e3);
     return rc;
 }
 
