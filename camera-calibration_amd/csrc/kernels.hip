@@ -5,18 +5,21 @@
 // monocular_circle.cpp:93-94, monocular_chessboard.cpp:315-317 and
 // binocular_chessboard.cpp:152-162.
 //
-// Work decomposition (all FP64 VALU, no MFMA: the blocks are 6x6 .. 18x18 rank-2 updates):
-//   * a view is owned by G consecutive lanes of one wavefront (G = 2..64, power of two);
-//     lane g handles points g, g+G, ...; image points are read in the caller's own layout
-//     (view-major float2), so the G lanes of a view read one contiguous run;
-//   * k_err         residuals only, one accumulator per lane;
-//   * k_jac_shared  the shared (intrinsic) block: JiT*Ji, JiT*e, eT*e accumulated per lane over
-//                   every point the lane sees, reduced once per workgroup (wave shuffles + LDS);
-//   * k_jac_view    the per-view blocks JeT*Je, JeT*e, JiT*Je accumulated per lane over the
-//                   lane's points, butterfly-reduced over the view's G lanes, stored SoA;
-//                   the pose stays in a 13-double axis-angle form so that the accumulators fit;
-//   * k_schur / k_backsub  one lane per view: 6x6 Cholesky elimination of the view block.
-// Reductions are fixed-order trees (no atomics), so results are bitwise reproducible.
+// Work decomposition (all FP64):
+//   * k_jac_fused   the whole Jacobian pass of a camera for column sets of up to nine intrinsics:
+//                   one wavefront per view, one lane per point; the normal-equation update is the
+//                   product A^T A of the view's row matrix A = [Ji | Je | e], accumulated by
+//                   v_mfma_f64_16x16x4_f64 from a per-wave LDS buffer (see the kernel's comment);
+//   * the G-lane kernels: a view is owned by G consecutive lanes of one wavefront (G = 2..64, power
+//     of two); lane g handles points g, g+G, ...; image points are read in the caller's own layout
+//     (view-major float2), so the G lanes of a view read one contiguous run:
+//       k_err / k_reproj  residuals only, one accumulator per lane;
+//       k_jac_shared      the shared (intrinsic) block JiT*Ji, JiT*e, eT*e, reduced once per workgroup;
+//       k_jac_view        the per-view blocks JeT*Je, JeT*e, JiT*Je, butterfly-reduced over the G lanes
+//     (the last two serve the rational column sets, whose columns do not fit one 16-wide tile);
+//   * k_schur / k_backsub  one lane per view: 6x6 Cholesky elimination of the view block;
+//   * k_colsum      every column sum of a pass in one launch, written where the host polls.
+// Reductions are fixed-order trees (no atomics on data), so results are bitwise reproducible.
 #include "kernels.hpp"
 
 #include <hip/hip_runtime.h>
@@ -364,10 +367,10 @@ __global__ __launch_bounds__(64) void k_pose_const(const double* pose, int nview
     store_pose_const(ps, pc + kPoseConstStride * (size_t)v);
 }
 
-template <class M, bool SHARED>
+template <class M, bool SHARED, bool MULTI>
 __global__ __launch_bounds__(kBlock, 3) void k_jac_fused(PassArgs a, CamParams cp, const int* __restrict__ off,
                                                          const double* __restrict__ pc, double* __restrict__ blk,
-                                                         double* __restrict__ part, int RS, int CH, int dbg) {
+                                                         double* __restrict__ part, int RS, int CH) {
     constexpr int NC = M::NC, NB = M::NBLK, NU = M::NU, NR = M::NRED_U;
     constexpr int CPOSE = NC, CRES = NC + 6, NCOL = NC + 7;
     static_assert(NCOL <= 16, "column set does not fit one 16x16 tile");
@@ -430,6 +433,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_jac_fused(PassArgs a, CamParams c
     // loads share their wait counter with the LDS reads of the matrix phase.
     int first = 0, np = 0;
     float2 mpt = make_float2(0.f, 0.f);
+    float bX = 0.f, bY = 0.f, bZ = 0.f;  // this lane's object point of the first chunk
     unsigned qword = 0;
     auto fetch = [&](int v) {
         if constexpr (SHARED) {
@@ -437,12 +441,17 @@ __global__ __launch_bounds__(kBlock, 3) void k_jac_fused(PassArgs a, CamParams c
         } else {
             first = off[v], np = off[v + 1] - first;
         }
-        if (lane < np && !(dbg & 8)) mpt = a.img[first + lane];
+        if (lane < np) {
+            mpt = a.img[first + lane];
+            if constexpr (!SHARED) {
+                const float* ob = a.obj + 3 * (size_t)(first + lane);
+                bX = ob[0], bY = ob[1], bZ = ob[2];
+            }
+        }
         const unsigned* qs = reinterpret_cast<const unsigned*>(pc + kPoseConstStride * (size_t)v);
         qword = qs[lane & 31];
     };
-    // with a shared board lane p always works on board point p
-    float bX = 0.f, bY = 0.f, bZ = 0.f;
+    // with a shared board lane p always works on board point p (of the first chunk)
     if constexpr (SHARED) {
         if (lane < a.board_np) bX = lds_dyn[3 * lane], bY = lds_dyn[3 * lane + 1], bZ = lds_dyn[3 * lane + 2];
     }
@@ -465,11 +474,10 @@ __global__ __launch_bounds__(kBlock, 3) void k_jac_fused(PassArgs a, CamParams c
     const int dst = (jt >> 1) + lane;  // in double2 units; RS is even
     int dirty = CH;                    // rows of points [n, dirty) hold an earlier view's values
     int npsum = 0;                     // points this wavefront has seen
-    while (valid) {
-        const int n = np;              // the launcher guarantees np <= CH <= 64
-        npsum += n;
-        const int tile_cur = tile;
-        if (lane < n && !(dbg & 1)) {
+    // Point phase of one chunk of at most CH points: lane p < n evaluates its point and writes its two
+    // rows of A; rows of an earlier, longer chunk are cleared.
+    auto point_phase = [&](int n, float2 m, float X, float Y, float Z) {
+        if (lane < n) {
             double qd[13];
 #pragma unroll
             for (int k = 0; k < 13; k++) {
@@ -479,14 +487,9 @@ __global__ __launch_bounds__(kBlock, 3) void k_jac_fused(PassArgs a, CamParams c
             PoseConst q;
             q.ax[0] = qd[0], q.ax[1] = qd[1], q.ax[2] = qd[2], q.c = qd[3], q.c1 = qd[4], q.s = qd[5];
             q.b1 = qd[6], q.b2 = qd[7], q.b3 = qd[8], q.b4 = qd[9], q.t[0] = qd[10], q.t[1] = qd[11], q.t[2] = qd[12];
-            float X = bX, Y = bY, Z = bZ;
-            if constexpr (!SHARED) {
-                const float* ob = a.obj + 3 * (size_t)(first + lane);
-                X = ob[0], Y = ob[1], Z = ob[2];
-            }
             PointOut<M> o;
             double jex[6], jey[6];
-            point_jacobian<M>(q, cp, (double)X, (double)Y, (double)Z, (double)mpt.x, (double)mpt.y, o, jex, jey);
+            point_jacobian<M>(q, cp, (double)X, (double)Y, (double)Z, (double)m.x, (double)m.y, o, jex, jey);
             static_for<0, NC>([&](auto ic_) {
                 constexpr int i = decltype(ic_)::value;
                 if constexpr (!(CONSTC && (i == ICX || i == ICY)))
@@ -496,44 +499,71 @@ __global__ __launch_bounds__(kBlock, 3) void k_jac_fused(PassArgs a, CamParams c
             for (int b = 0; b < 6; b++) lds2[dst + ((slot(CPOSE + b) * RS) >> 1)] = make_double2(jex[b], jey[b]);
             lds2[dst + ((slot(CRES) * RS) >> 1)] = make_double2(o.ex, o.ey);
         }
-        if (n < dirty) {  // rows past this view's last point must read as zero (wave-uniform branch)
+        if (n < dirty) {  // rows past the chunk's last point must read as zero (wave-uniform branch)
             if (lane >= n && lane < dirty) {
 #pragma unroll
                 for (int c = 0; c < NCOL - (CONSTC ? 2 : 0); c++) lds2[dst + ((c * RS) >> 1)] = make_double2(0., 0.);
             }
         }
         dirty = n;
-        // the next view's loads go out here, ahead of the matrix phase
+    };
+    // Matrix phase: sixteen rows per trip (this lane feeds rows 8m + 2rq and 8m + 2rq + 1 of column
+    // `col` in step m), the two operand pairs in alternating registers (no copies); the read of the step
+    // after is in flight while a step multiplies.  CH is a multiple of 8, so the rows up to the next
+    // multiple of 16 exist and are zero.
+    auto matrix_phase = [&](int n, double4_t& acc) {
+        __builtin_amdgcn_wave_barrier();
+        const int npairs = (2 * n + 15) >> 4;
+        const int last = src + 8 * (npairs - 1) + 4;
+        int nxt = src + 4;
+        double2 pa = lds2r[src];
+        for (int k = 0; k < npairs; k++) {
+            double2 pb = lds2r[nxt];
+            nxt = nxt + 4 < last ? nxt + 4 : last;
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.x, pa.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.y, pa.y, acc, 0, 0, 0);
+            pa = lds2r[nxt];
+            nxt = nxt + 4 < last ? nxt + 4 : last;
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pb.x, pb.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pb.y, pb.y, acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();  // the reads are done before the buffer is overwritten
+    };
+    auto advance = [&]() {  // the next view's loads go out ahead of the matrix phase
         tile += gridDim.x;
         v = __builtin_amdgcn_readfirstlane(tile * kTileViews + w);
         valid = tile < ntiles && v < a.nviews;
         if (valid) fetch(v);
-        __builtin_amdgcn_wave_barrier();
-        // eight rows per step: this lane feeds rows 8m + 2rq and 8m + 2rq + 1 of column `col`;
-        // the read of step m + 1 is in flight while step m multiplies
-        const int npairs = (dbg & 2) ? 0 : (2 * n + 15) >> 4;
+    };
+    while (valid) {
+        const int tile_cur = tile, vfirst = first, vnp = np;
+        npsum += vnp;
         double4_t acc = {0., 0., 0., 0.};
-        // sixteen rows per trip, the two operand pairs in alternating registers (no copies); the read
-        // of the step after is in flight while a step multiplies.  CH is a multiple of 8, so the rows
-        // up to the next multiple of 16 exist and are zero.
-        {
-            const int last = src + 8 * (npairs - 1) + 4;
-            int nxt = src + 4;
-            double2 pa = lds2r[src];
-            for (int k = 0; k < npairs; k++) {
-                double2 pb = lds2r[nxt];
-                nxt = nxt + 4 < last ? nxt + 4 : last;
-                __builtin_amdgcn_sched_barrier(0);
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.x, pa.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.y, pa.y, acc, 0, 0, 0);
-                pa = lds2r[nxt];
-                nxt = nxt + 4 < last ? nxt + 4 : last;
-                __builtin_amdgcn_sched_barrier(0);
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pb.x, pb.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pb.y, pb.y, acc, 0, 0, 0);
+        if constexpr (!MULTI) {  // the launcher guarantees np <= CH <= 64
+            point_phase(vnp, mpt, bX, bY, bZ);
+            advance();
+            matrix_phase(vnp, acc);
+        } else {
+            for (int p0 = 0; p0 < vnp; p0 += CH) {
+                const int n = vnp - p0 < CH ? vnp - p0 : CH;
+                float2 m = mpt;
+                float X = bX, Y = bY, Z = bZ;
+                if (p0 > 0 && lane < n) {  // later chunks are not fetched ahead
+                    m = a.img[vfirst + p0 + lane];
+                    if constexpr (SHARED) {
+                        X = lds_dyn[3 * (p0 + lane)], Y = lds_dyn[3 * (p0 + lane) + 1], Z = lds_dyn[3 * (p0 + lane) + 2];
+                    } else {
+                        const float* ob = a.obj + 3 * (size_t)(vfirst + p0 + lane);
+                        X = ob[0], Y = ob[1], Z = ob[2];
+                    }
+                }
+                point_phase(n, m, X, Y, Z);
+                if (p0 + CH >= vnp) advance();
+                matrix_phase(n, acc);
             }
         }
-        __builtin_amdgcn_wave_barrier();  // the reads are done before the next view overwrites the buffer
         usum += acc;
         // Unconditional buffer stores: lanes whose register holds nothing to keep carry an offset
         // past the tile, which the range check drops.  (Stores under a branch would hide their
@@ -544,7 +574,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_jac_fused(PassArgs a, CamParams c
         for (int r = 0; r < 4; r++) {
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
             double d = acc[r];
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, d), rsrc, (dbg & 4) ? 0x7fffffff : voff[r], 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, d), rsrc, voff[r], 0, 0);
         }
     }
     double* po = part + (size_t)(blockIdx.x * kWaves + w) * NR;
@@ -720,12 +750,17 @@ static void launch_jac_fused(const PassArgs& a, const CamParams& cp, const doubl
                              hipStream_t st) {
     constexpr bool const_cols = M::index_of(I_CX) >= 0 && M::index_of(I_CY) == M::index_of(I_CX) + 1;
     FusedGeom g = fused_geom(a.maxnp, a.shared_board != 0, a.board_np, const_cols);
-    int dbg = 0;
-    if (const char* e = std::getenv("CCALIB_FUSED_DBG")) dbg = std::atoi(e);
+    auto go = [&](auto shared, auto multi) {
+        k_jac_fused<M, decltype(shared)::value, decltype(multi)::value>
+            <<<dim3(grid), dim3(kBlock), g.lds_bytes, st>>>(a, cp, a.off, pc, blk, part, g.RS, g.CH);
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    const bool multi = a.maxnp > g.CH;  // views longer than one chunk of 64 points
     if (a.shared_board)
-        k_jac_fused<M, true><<<dim3(grid), dim3(kBlock), g.lds_bytes, st>>>(a, cp, a.off, pc, blk, part, g.RS, g.CH, dbg);
+        multi ? go(T{}, T{}) : go(T{}, F{});
     else
-        k_jac_fused<M, false><<<dim3(grid), dim3(kBlock), g.lds_bytes, st>>>(a, cp, a.off, pc, blk, part, g.RS, g.CH, dbg);
+        multi ? go(F{}, T{}) : go(F{}, F{});
 }
 template <int NC>
 static void launch_schur(const double* blk, int npad, int nviews, double lambda, double* part, hipStream_t st) {
@@ -822,7 +857,6 @@ FusedGeom fused_geom(int maxnp, bool shared_board, int board_np, bool const_cols
     size_t board_f = shared_board ? (size_t)(3 * board_np + 3) / 4 * 4 : 0;
     // 14 private columns per wavefront + 2 shared ones when the principal point is in the set, else 16
     g.lds_bytes = (unsigned)(sizeof(float) * board_f + sizeof(double) * (const_cols ? kWaves * 14 + 2 : kWaves * 16) * (size_t)g.RS);
-    if (const char* e = std::getenv("CCALIB_LDS_PAD")) g.lds_bytes = std::max<unsigned>(g.lds_bytes, std::atoi(e));
     return g;
 }
 

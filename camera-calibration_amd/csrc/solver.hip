@@ -576,8 +576,7 @@ int ccalib_solver_create(ccalib_solver** out, int device, int ncams, int nviews,
         s->grid_fused = std::max(1, std::min((nviews + kTileViews - 1) / kTileViews, std::atoi(e)));
     if (const char* e = std::getenv("CCALIB_NO_FUSED")) s->use_fused = std::atoi(e) == 0;
     if (const char* e = std::getenv("CCALIB_NO_AHEAD")) s->speculate = std::atoi(e) == 0;
-    // one wavefront evaluates a whole view at once, one point per lane
-    if (s->maxnp > 64 || fused_geom(s->maxnp, s->shared_board, s->board_np).lds_bytes > 64 * 1024) s->use_fused = false;
+    if (fused_geom(s->maxnp, s->shared_board, s->board_np).lds_bytes > 64 * 1024) s->use_fused = false;
     s->nblk64 = (nviews + 63) / 64;
     s->npad = (nviews + 63) / 64 * 64;
     HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
