@@ -263,10 +263,52 @@ __device__ __forceinline__ void point_jacobian(const PoseConst& q, const CamPara
     }
 }
 
+// Sum over the 64 lanes of a wavefront, returned in every lane.  Within rows of 16 lanes the butterfly
+// runs on DPP moves (quad permutes, then the half-row and row mirrors), the four row sums are read out
+// with v_readlane: no LDS crossbar traffic and nothing to wait for.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
+    v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);  // row_half_mirror
+    v += dpp_move<0x140>(v);  // row_mirror: every lane of a row now holds the row's sum
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+    double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+    double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+// Sums N per-lane values over the 64 lanes of a single-wavefront workgroup and stores them to out[0..N):
+// the values go through LDS transposed, 32 at a time, and lane k adds up the 64 contributions of value k
+// in a fixed order.  sm: 32 * 65 doubles (the odd row length keeps the column reads off one bank).
+template <int N>
+__device__ __forceinline__ void lanes_reduce_store(const double (&acc)[N], double* sm, double* out) {
+    const int lane = threadIdx.x & 63;
+    static_for<0, (N + 31) / 32>([&](auto cc) {
+        constexpr int c0 = decltype(cc)::value * 32;
+        constexpr int n = N - c0 < 32 ? N - c0 : 32;
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+        for (int k = 0; k < n; k++) sm[k * 65 + lane] = acc[c0 + k];
+        __builtin_amdgcn_wave_barrier();
+        if (lane < n) {
+            double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+            for (int j = 0; j < 64; j += 4) {
+                s0 += sm[lane * 65 + j], s1 += sm[lane * 65 + j + 1];
+                s2 += sm[lane * 65 + j + 2], s3 += sm[lane * 65 + j + 3];
+            }
+            out[c0 + lane] = (s0 + s1) + (s2 + s3);
+        }
+    });
 }
 
 // In-place lower Cholesky of a symmetric 6x6 given by its upper triangle packed row-major

@@ -600,15 +600,17 @@ __global__ __launch_bounds__(64) void k_schur(const double* blk, int npad, int n
     for (int k = 0; k < 21; k++) Vu[k] = blk[blk_index(NB, k, vv)];
 #pragma unroll
     for (int k = 0; k < 6; k++) y[k] = blk[blk_index(NB, 21 + k, vv)];
+    // every load of the view goes out before the (long, serial) factorisation starts
+#pragma unroll
+    for (int i = 0; i < NC; i++)
+#pragma unroll
+        for (int b = 0; b < 6; b++) Z[i][b] = blk[blk_index(NB, 27 + 6 * i + b, vv)];
     bool ok = chol6(Vu, lambda, L, invd) && live;
     chol6_fwd(L, invd, y);
 #pragma unroll
-    for (int i = 0; i < NC; i++) {
-#pragma unroll
-        for (int b = 0; b < 6; b++) Z[i][b] = blk[blk_index(NB, 27 + 6 * i + b, vv)];
-        chol6_fwd(L, invd, Z[i]);  // Z_i = L^-1 W_i^T, so W V'^-1 W^T = Z Z^T
-    }
-    double* out = part + (size_t)blockIdx.x * NS;
+    for (int i = 0; i < NC; i++) chol6_fwd(L, invd, Z[i]);  // Z_i = L^-1 W_i^T, so W V'^-1 W^T = Z Z^T
+    __shared__ double sm[32 * 65];
+    double acc[NS];
     int k = 0;
 #pragma unroll
     for (int i = 0; i < NC; i++)
@@ -617,19 +619,16 @@ __global__ __launch_bounds__(64) void k_schur(const double* blk, int npad, int n
             double s = 0;
 #pragma unroll
             for (int b = 0; b < 6; b++) s += Z[i][b] * Z[j][b];
-            s = wave_sum(ok ? s : 0.);
-            if (threadIdx.x == 0) out[k] = s;
-            k++;
+            acc[k++] = ok ? s : 0.;
         }
 #pragma unroll
     for (int i = 0; i < NC; i++) {
         double s = 0;
 #pragma unroll
         for (int b = 0; b < 6; b++) s += Z[i][b] * y[b];
-        s = wave_sum(ok ? s : 0.);
-        if (threadIdx.x == 0) out[k] = s;
-        k++;
+        acc[k++] = ok ? s : 0.;
     }
+    lanes_reduce_store<NS>(acc, sm, part + (size_t)blockIdx.x * NS);
 }
 
 // trial pose = committed pose - V'^-1 (ge - W^T dc).  part per workgroup: sum |delta|^2, sum |pose_prev|^2.

@@ -1,4 +1,4 @@
 set -e
-timeout -k 10 120 python tools/kernel_bench.py 100000 200
-CCALIB_GRID_FUSED=512 timeout -k 10 120 python tools/kernel_bench.py 100000 200
-CCALIB_TIMING=1 timeout -k 10 300 python bench.py --steps 20 --warmup 3 --no-cpu | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['rms_px'], d['roofline']['launch_ms'])"
+timeout -k 10 200 python tools/stereo_bench.py 10000 20
+timeout -k 10 200 python tools/stereo_bench.py 100000 20
+CCALIB_NO_FUSED=1 CCALIB_NO_AHEAD=1 timeout -k 10 200 python tools/stereo_bench.py 100000 20
