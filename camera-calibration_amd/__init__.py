@@ -118,6 +118,27 @@ def stereo_calibrate(obj_views, img1, img2, K1, d1, K2, d2, size, flags,
                 device_ms=st.device_ms)
 
 
+def write_mono_yaml(path, size, K, dist, rvecs, tvecs):
+    """The file monocular_chessboard.cpp:321-328 writes: imageSize, M, D, R, t (cv::FileStorage YAML)."""
+    lib = capi.load()
+    d = np.ascontiguousarray(dist, dtype=np.float64).reshape(-1)
+    rv = np.ascontiguousarray(rvecs, dtype=np.float64).reshape(-1, 3)
+    tv = np.ascontiguousarray(tvecs, dtype=np.float64).reshape(-1, 3)
+    capi.check(lib.ccalib_write_mono_yaml(str(path).encode(), C.c_int(size[0]), C.c_int(size[1]),
+                                          _p(np.ascontiguousarray(K, dtype=np.float64).reshape(-1)), _p(d), C.c_int(d.size),
+                                          C.c_int(rv.shape[0]), _p(rv), _p(tv)))
+
+
+def write_stereo_yaml(intrinsics_path, extrinsics_path, size, K1, d1, K2, d2, R, T, E=None, F=None):
+    """The two files binocular_chessboard.cpp:203-210 and :234-241 write (M1 D1 M2 D2; imageSize R T [E F])."""
+    lib = capi.load()
+    f = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64).reshape(-1)
+    a1, a2 = f(d1), f(d2)
+    capi.check(lib.ccalib_write_stereo_yaml(str(intrinsics_path).encode(), str(extrinsics_path).encode(),
+                                            C.c_int(size[0]), C.c_int(size[1]), _p(f(K1)), _p(a1), C.c_int(a1.size),
+                                            _p(f(K2)), _p(a2), C.c_int(a2.size), _p(f(R)), _p(f(T)), _p(f(E)), _p(f(F))))
+
+
 def reprojection_error(obj_views, img_views, K, dist, rvecs, tvecs, want_points=False):
     """projectPoints over all views + the RMS the reference recomputes from it.
     Returns (total_rms, per_view_rms[, projected (T,2) float32])."""

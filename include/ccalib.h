@@ -129,6 +129,22 @@ int ccalib_init_camera_matrix_2d(int nviews, const int* npts, const float* obj_x
                                  const float* img_uv, int width, int height, double aspect,
                                  double* K);
 
+/*
+ * The result files the reference writes with cv::FileStorage, in the same "%YAML:1.0" dialect
+ * (!!opencv-matrix nodes), readable by FileStorage::READ (binocular_chessboard.cpp:285-295).
+ *   mono    imageSize, M, D, R (sequence of 3x1 rvecs), t (sequence of 3x1 tvecs)
+ *           (monocular_chessboard.cpp:321-328)
+ *   stereo  intrinsics file M1, D1, M2, D2 (binocular_chessboard.cpp:203-210); extrinsics file
+ *           imageSize, R, T and, when given, E, F (binocular_chessboard.cpp:234-241; the R1, R2, P1,
+ *           P2, Q entries there come from cv::stereoRectify, which is not part of this library)
+ */
+int ccalib_write_mono_yaml(const char* path, int width, int height, const double* K, const double* dist,
+                           int ndist, int nviews, const double* rvecs, const double* tvecs);
+int ccalib_write_stereo_yaml(const char* intrinsics_path, const char* extrinsics_path, int width, int height,
+                             const double* K1, const double* dist1, int ndist1, const double* K2,
+                             const double* dist2, int ndist2, const double* R, const double* T,
+                             const double* E, const double* F);
+
 /* ---- solver level: device-resident problem + host LM driver ------------------------------ */
 typedef struct ccalib_solver ccalib_solver;
 

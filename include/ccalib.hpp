@@ -170,4 +170,24 @@ inline double computeReprojectionErrors(const std::vector<std::vector<Point3f>>&
     return total;
 }
 
+// The result files of the reference (cv::FileStorage YAML): monocular_chessboard.cpp:321-328 and
+// binocular_chessboard.cpp:203-210, :234-241.
+inline void writeMonoYaml(const std::string& path, Size imageSize, const Mat& M, const Mat& D, const std::vector<Mat>& rvecs,
+                          const std::vector<Mat>& tvecs) {
+    int n = (int)rvecs.size();
+    std::vector<double> rv((size_t)3 * n), tv((size_t)3 * n);
+    for (int i = 0; i < n; i++)
+        for (int c = 0; c < 3; c++) rv[(size_t)3 * i + c] = rvecs[i].v[c], tv[(size_t)3 * i + c] = tvecs[i].v[c];
+    detail::check(ccalib_write_mono_yaml(path.c_str(), imageSize.width, imageSize.height, M.v.data(), D.v.data(),
+                                         (int)D.total(), n, rv.data(), tv.data()));
+}
+inline void writeStereoYaml(const std::string& intrinsicsPath, const std::string& extrinsicsPath, Size imageSize,
+                            const Mat& M1, const Mat& D1, const Mat& M2, const Mat& D2, const Mat& R, const Mat& T,
+                            const Mat& E, const Mat& F) {
+    detail::check(ccalib_write_stereo_yaml(intrinsicsPath.c_str(), extrinsicsPath.c_str(), imageSize.width, imageSize.height,
+                                           M1.v.data(), D1.v.data(), (int)D1.total(), M2.v.data(), D2.v.data(),
+                                           (int)D2.total(), R.v.data(), T.v.data(), E.empty() ? nullptr : E.v.data(),
+                                           F.empty() ? nullptr : F.v.data()));
+}
+
 }  // namespace ccalib

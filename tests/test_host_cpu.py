@@ -97,3 +97,47 @@ def test_sharded_lm_over_two_gloo_ranks():
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "SHARDED_OK" in out.stdout
+
+
+def _load_opencv_yaml(path):
+    """Reads cv::FileStorage YAML 1.0 (the '%YAML:1.0' directive and '!!opencv-matrix' nodes) with PyYAML."""
+    import yaml
+
+    class Loader(yaml.SafeLoader):
+        pass
+
+    def matrix(loader, node):
+        m = loader.construct_mapping(node, deep=True)
+        assert m["dt"] == "d"
+        return np.array(m["data"], dtype=np.float64).reshape(m["rows"], m["cols"])
+
+    Loader.add_constructor("tag:yaml.org,2002:opencv-matrix", matrix)
+    text = open(path).read()
+    assert text.startswith("%YAML:1.0\n---\n")
+    return yaml.load(text.split("---\n", 1)[1], Loader=Loader)
+
+
+def test_yaml_result_files_round_trip(pkg, tmp_path):
+    """The files the reference writes after calibrating (monocular_chessboard.cpp:321-328,
+    binocular_chessboard.cpp:203-210 and :234-241): same keys, same node types, values bit-exact."""
+    rng = np.random.default_rng(5)
+    K = np.array([[812.123456789, 0, 322.5], [0, 806.25, 238.0], [0, 0, 1.0]])
+    D = rng.normal(size=5) * 0.1
+    rv, tv = rng.normal(size=(7, 3)), rng.normal(size=(7, 3)) * 100
+    p = tmp_path / "trinsics.yml"
+    pkg.write_mono_yaml(p, (640, 480), K, D, rv, tv)
+    y = _load_opencv_yaml(p)
+    assert list(y) == ["imageSize", "M", "D", "R", "t"] and y["imageSize"] == [640, 480]
+    assert np.array_equal(y["M"], K) and np.array_equal(y["D"].ravel(), D) and y["D"].shape == (5, 1)
+    assert len(y["R"]) == 7 and all(m.shape == (3, 1) for m in y["R"])
+    assert np.array_equal(np.hstack(y["R"]).T, rv) and np.array_equal(np.hstack(y["t"]).T, tv)
+    pi, pe = tmp_path / "intrinsics.yml", tmp_path / "extrinsics.yml"
+    D14 = np.r_[D, rng.normal(size=3) * 0.01, np.zeros(6)]
+    R, T = np.eye(3) + 1e-3 * rng.normal(size=(3, 3)), np.array([-60.0, 0.5, 1.0])
+    pkg.write_stereo_yaml(pi, pe, (640, 480), K, D14, K * 1.01, D14 * 0.5, R, T, E=R * 2, F=R * 3)
+    yi, ye = _load_opencv_yaml(pi), _load_opencv_yaml(pe)
+    assert list(yi) == ["M1", "D1", "M2", "D2"] and yi["D1"].shape == (1, 14)
+    assert np.array_equal(yi["M2"], K * 1.01) and np.array_equal(yi["D2"].ravel(), D14 * 0.5)
+    assert list(ye) == ["imageSize", "R", "T", "E", "F"] and np.array_equal(ye["R"], R) and np.array_equal(ye["T"].ravel(), T)
+    with pytest.raises(pkg.CcalibError):
+        pkg.write_mono_yaml(tmp_path / "no_such_dir" / "x.yml", (1, 1), K, D, rv, tv)
