@@ -202,10 +202,33 @@ class Solver:
         intr = np.ascontiguousarray(intr, dtype=np.float64).reshape(self.ncams, 18)
         imask = np.ascontiguousarray(imask, dtype=np.uint8).reshape(self.ncams, 18)
         asp = np.zeros(self.ncams) if aspect is None else np.ascontiguousarray(aspect, dtype=np.float64).reshape(self.ncams)
-        rt = np.ascontiguousarray(rt, dtype=np.float64).reshape(self.nviews, 6)
+        rt = None if rt is None else np.ascontiguousarray(rt, dtype=np.float64).reshape(self.nviews, 6)
         lrp = None if lr is None else np.ascontiguousarray(lr, dtype=np.float64).reshape(6)
         capi.check(self._lib.ccalib_solver_set_start(self._h, _p(intr), _p(imask), _p(asp),
                                                      C.c_int(1 if same_focal else 0), _p(rt), _p(lrp)))
+
+    def init_intrinsics(self, size, cam=0, aspect=0.0):
+        """cv::initCameraMatrix2D on the device for camera `cam` (summed over ranks in a sharded run)."""
+        A = np.zeros(9)
+        capi.check(self._lib.ccalib_solver_init_intrinsics(self._h, C.c_int(cam), C.c_int(size[0]), C.c_int(size[1]),
+                                                           C.c_double(aspect), _p(A)))
+        return A.reshape(3, 3)
+
+    def init_poses(self, K, dist=None, cam=0, want=True):
+        """cvFindExtrinsicCameraParams2 for every view on the device; camera 0's poses stay there as the
+        starting poses (set_start(rt=None)).  Returns (nviews, 6) r|t when want."""
+        d = np.zeros(14)
+        if dist is not None:
+            d[:np.size(dist)] = np.ravel(dist)
+        rt = np.zeros((self.nviews, 6)) if want else None
+        capi.check(self._lib.ccalib_solver_init_poses(self._h, C.c_int(cam),
+                                                      _p(np.ascontiguousarray(K, dtype=np.float64).reshape(-1)), _p(d), _p(rt)))
+        return rt
+
+    def init_relative_pose(self):
+        lr = np.zeros(6)
+        capi.check(self._lib.ccalib_solver_init_relative_pose(self._h, _p(lr)))
+        return lr
 
     def use_rccl(self, nranks, rank, unique_id: bytes):
         buf = C.create_string_buffer(unique_id, 128)

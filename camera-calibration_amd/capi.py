@@ -21,6 +21,7 @@ SYMBOLS = [
     "ccalib_solver_run", "ccalib_solver_get", "ccalib_solver_num_shared",
     "ccalib_solver_eval_error", "ccalib_solver_eval_jacobian", "ccalib_solver_fetch_blocks",
     "ccalib_solver_reduce", "ccalib_solver_time_kernels", "ccalib_lm_run",
+    "ccalib_solver_init_intrinsics", "ccalib_solver_init_poses", "ccalib_solver_init_relative_pose",
 ]
 
 OK, ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_STATE, ERR_NUMERIC = range(7)

@@ -11,7 +11,7 @@
 #include <vector>
 
 #include "ccalib.h"
-#include "host_init.hpp"
+#include "host_rodrigues.hpp"
 #include "host_util.hpp"
 
 using namespace ccalib;
@@ -71,8 +71,11 @@ int ccalib_init_camera_matrix_2d(int nviews, const int* npts, const float* obj_x
     if (nviews < 1 || !npts || !obj_xyz || !img_uv || !K) return set_error(CCALIB_ERR_ARG, "initCameraMatrix2D: bad arguments");
     for (int i = 0; i < nviews; i++)
         if (npts[i] < 4) return set_error(CCALIB_ERR_ARG, "view %d has fewer than 4 points", i);
-    host_init_intrinsics(nviews, npts, obj_xyz, img_uv, width, height, aspect, K);
-    return CCALIB_OK;
+    bool shared = views_share_board(nviews, npts, obj_xyz);
+    SolverGuard g;
+    int rc = ccalib_solver_create(&g.s, 0, 1, nviews, npts, obj_xyz, shared ? 1 : 0, img_uv, nullptr);
+    if (rc) return rc;
+    return ccalib_solver_init_intrinsics(g.s, 0, width, height, aspect, K);
 }
 
 int ccalib_calibrate_camera(int nviews, const int* npts, const float* obj_xyz, const float* img_uv, int width,
@@ -94,7 +97,8 @@ int ccalib_calibrate_camera(int nviews, const int* npts, const float* obj_xyz, c
         if (ndist < 5) flags |= CCALIB_FIX_K3;
         flags |= CCALIB_FIX_K4 | CCALIB_FIX_K5 | CCALIB_FIX_K6;
     }
-    std::vector<float> obj(obj_xyz, obj_xyz + 3 * total);
+    const float* obj = obj_xyz;
+    std::vector<float> flattened;  // only when the rig's Z has to be cleared
     double A[9], k[14] = {0}, aspect = 0;
     std::memcpy(A, K, sizeof(A));
     if (flags & CCALIB_USE_INTRINSIC_GUESS) {
@@ -114,12 +118,20 @@ int ccalib_calibrate_camera(int nviews, const int* npts, const float* obj_xyz, c
         for (size_t i = 0; i < total; i++) sq += (obj[3 * i + 2] - mean) * (obj[3 * i + 2] - mean);
         if (std::fabs(mean) > 1e-5 || std::sqrt(sq / (double)total) > 1e-5)
             return set_error(CCALIB_ERR_ARG, "for non-planar calibration rigs the initial intrinsic matrix must be specified");
-        for (size_t i = 0; i < total; i++) obj[3 * i + 2] = 0.f;
+        if (sq != 0 || mean != 0) {
+            flattened.assign(obj_xyz, obj_xyz + 3 * total);
+            for (size_t i = 0; i < total; i++) flattened[3 * i + 2] = 0.f;
+            obj = flattened.data();
+        }
         if (flags & CCALIB_FIX_ASPECT_RATIO) aspect = A[0] / A[4];
     }
     if ((flags & CCALIB_FIX_ASPECT_RATIO) && !(aspect >= 0.01 && aspect <= 100.))
         return set_error(CCALIB_ERR_ARG, "the specified aspect ratio (= cameraMatrix[0][0] / cameraMatrix[1][1]) is incorrect");
-    if (!(flags & CCALIB_USE_INTRINSIC_GUESS)) host_init_intrinsics(nviews, npts, obj.data(), img_uv, width, height, aspect, A);
+    // the points go to the device once; initialisation and the LM loop both run there
+    bool shared = views_share_board(nviews, npts, obj);
+    SolverGuard g;
+    if ((rc = ccalib_solver_create(&g.s, 0, 1, nviews, npts, obj, shared ? 1 : 0, img_uv, nullptr))) return rc;
+    if (!(flags & CCALIB_USE_INTRINSIC_GUESS) && (rc = ccalib_solver_init_intrinsics(g.s, 0, width, height, aspect, A))) return rc;
 
     double intr[18];
     unsigned char mask[18];
@@ -128,17 +140,11 @@ int ccalib_calibrate_camera(int nviews, const int* npts, const float* obj_xyz, c
     if (flags & CCALIB_ZERO_TANGENT_DIST) intr[6] = intr[7] = 0;
     flags = intrinsic_mask(flags, mask);
 
-    bool shared = views_share_board(nviews, npts, obj.data());
+    // starting poses: the caller's, or cvFindExtrinsicCameraParams2 per view (left on the device)
+    if (!init_rt && (rc = ccalib_solver_init_poses(g.s, 0, A, k, nullptr))) return rc;
     std::vector<double> rt((size_t)6 * nviews);
-    if (init_rt)
-        std::memcpy(rt.data(), init_rt, sizeof(double) * rt.size());
-    else
-        host_init_poses(nviews, npts, obj.data(), shared, img_uv, A, k, rt.data());
-
-    SolverGuard g;
-    if ((rc = ccalib_solver_create(&g.s, 0, 1, nviews, npts, obj.data(), shared ? 1 : 0, img_uv, nullptr))) return rc;
     double asp[1] = {(flags & CCALIB_FIX_ASPECT_RATIO) ? aspect : 0.};
-    if ((rc = ccalib_solver_set_start(g.s, intr, mask, asp, 0, rt.data(), nullptr))) return rc;
+    if ((rc = ccalib_solver_set_start(g.s, intr, mask, asp, 0, init_rt, nullptr))) return rc;
     ccalib_stats st;
     int method = (flags & CCALIB_USE_LU) ? 0 : 1;
     if ((rc = ccalib_solver_run(g.s, term_type, max_iter, eps, method, &st))) return rc;
@@ -222,35 +228,17 @@ int ccalib_stereo_calibrate(int nviews, const int* npts, const float* obj_xyz, c
         }
     }
     bool shared = views_share_board(nviews, npts, obj_xyz);
-    std::vector<double> rt((size_t)6 * nviews);
+    SolverGuard g;
+    if ((rc = ccalib_solver_create(&g.s, 0, 2, nviews, npts, obj_xyz, shared ? 1 : 0, img1_uv, img2_uv))) return rc;
     double lr[6];
-    if (init_rt && init_lr) {
-        std::memcpy(rt.data(), init_rt, sizeof(double) * rt.size());
+    const bool given = init_rt && init_lr;
+    if (given) {
         std::memcpy(lr, init_lr, sizeof(lr));
     } else {
         // per-view, per-camera planar poses; relative pose = per-component median over views
-        std::vector<double> rt2((size_t)6 * nviews), RT0((size_t)6 * nviews);
-        host_init_poses(nviews, npts, obj_xyz, shared, img1_uv, Ak[0], dk[0], rt.data());
-        host_init_poses(nviews, npts, obj_xyz, shared, img2_uv, Ak[1], dk[1], rt2.data());
-        for (int i = 0; i < nviews; i++) {
-            double R0[9], R1[9], Rr[9], om[3];
-            host_rodrigues_v2m(rt.data() + 6 * i, R0, nullptr);
-            host_rodrigues_v2m(rt2.data() + 6 * i, R1, nullptr);
-            for (int a = 0; a < 3; a++)
-                for (int b = 0; b < 3; b++) Rr[a * 3 + b] = R1[a * 3] * R0[b * 3] + R1[a * 3 + 1] * R0[b * 3 + 1] + R1[a * 3 + 2] * R0[b * 3 + 2];
-            host_rodrigues_m2v(Rr, om);
-            const double* t0 = rt.data() + 6 * i + 3;
-            const double* t1 = rt2.data() + 6 * i + 3;
-            for (int a = 0; a < 3; a++) {
-                RT0[(size_t)a * nviews + i] = om[a];
-                RT0[(size_t)(3 + a) * nviews + i] = t1[a] - (Rr[a * 3] * t0[0] + Rr[a * 3 + 1] * t0[1] + Rr[a * 3 + 2] * t0[2]);
-            }
-        }
-        for (int a = 0; a < 6; a++) {
-            double* col = RT0.data() + (size_t)a * nviews;
-            std::sort(col, col + nviews);
-            lr[a] = nviews % 2 ? col[nviews / 2] : (col[nviews / 2 - 1] + col[nviews / 2]) * 0.5;
-        }
+        for (int c = 0; c < 2; c++)
+            if ((rc = ccalib_solver_init_poses(g.s, c, Ak[c], dk[c], nullptr))) return rc;
+        if ((rc = ccalib_solver_init_relative_pose(g.s, lr))) return rc;
     }
     double intr[36];
     for (int c = 0; c < 2; c++) {
@@ -259,9 +247,8 @@ int ccalib_stereo_calibrate(int nviews, const int* npts, const float* obj_xyz, c
         ip[0] = Ak[c][0], ip[1] = Ak[c][4], ip[2] = Ak[c][2], ip[3] = Ak[c][5];
         std::memcpy(ip + 4, dk[c], sizeof(dk[c]));
     }
-    SolverGuard g;
-    if ((rc = ccalib_solver_create(&g.s, 0, 2, nviews, npts, obj_xyz, shared ? 1 : 0, img1_uv, img2_uv))) return rc;
-    if ((rc = ccalib_solver_set_start(g.s, intr, mask, aspect, (flags & CCALIB_SAME_FOCAL_LENGTH) ? 1 : 0, rt.data(), lr)))
+    if ((rc = ccalib_solver_set_start(g.s, intr, mask, aspect, (flags & CCALIB_SAME_FOCAL_LENGTH) ? 1 : 0,
+                                      given ? init_rt : nullptr, lr)))
         return rc;
     ccalib_stats st;
     int method = (flags & CCALIB_USE_LU) ? 0 : 1;

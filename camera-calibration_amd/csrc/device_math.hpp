@@ -106,7 +106,7 @@ __device__ __forceinline__ void rodrigues(const double r[3], double R[9], double
         for (int i = 0; i < 3; i++) {
             double ri = ax[i];
             double a0 = -s * ri, a1 = (s - 2 * c1 * it) * ri, a2 = c1 * it;
-            double a3 = (c - s * it) * ri, a4 = s * it;
+            double a3 = (c - s * it) * ri;
             // d(rr^T)/d(axis_i): row i and column i hold the axis, doubled on the diagonal
             double drrt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
             for (int k = 0; k < 3; k++) {

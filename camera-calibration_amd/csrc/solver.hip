@@ -22,6 +22,7 @@
 
 #include "ccalib.h"
 #include "host_util.hpp"
+#include "init_kernels.hpp"
 #include "kernels.hpp"
 #include "stereo_kernels.hpp"
 
@@ -64,6 +65,10 @@ struct ccalib_solver {
     double* d_cmp[2] = {nullptr, nullptr};                  // stereo: per-view composition Jacobians (SoA), per buffer
     double* d_blk[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [camera][buffer]
     double* d_pc = nullptr;  // nviews x kPoseConstStride: poses in the form the fused Jacobian kernel reads
+    // initialisation (ccalib_solver_init_*): per-view status words, per-camera "poses are on the device" marks
+    int* d_status = nullptr;
+    double* d_pose_init1 = nullptr;  // stereo: camera-1 planar poses until the relative pose has been taken
+    bool poses_ready[2] = {false, false};
     bool pc_fresh = false;   // d_pc matches d_pose_cur
     // Partial results of the kernels of one pass: a bump-allocated arena, reduced by ONE column-sum
     // launch per pass whose output goes straight to pinned host memory; the host polls a flag there.
@@ -618,6 +623,7 @@ void ccalib_solver_destroy(ccalib_solver* s) {
     (void)hipFree(s->d_pose_prev), (void)hipFree(s->d_pose_cur), (void)hipFree(s->d_pose3);
     for (int b = 0; b < 2; b++) (void)hipFree(s->d_cmp[b]), (void)hipFree(s->d_blk[0][b]), (void)hipFree(s->d_blk[1][b]);
     (void)hipFree(s->d_pc), (void)hipFree(s->d_part), (void)hipFree(s->d_red);
+    (void)hipFree(s->d_status), (void)hipFree(s->d_pose_init1);
     if (s->h_red) (void)hipHostFree(s->h_red);
     if (s->h_flag) (void)hipHostFree(s->h_flag);
     (void)hipFree(s->d_counter);
@@ -627,7 +633,9 @@ void ccalib_solver_destroy(ccalib_solver* s) {
 
 int ccalib_solver_set_start(ccalib_solver* s, const double* intr, const unsigned char* imask, const double* aspect,
                             int same_focal, const double* rt, const double* lr) {
-    if (!s || !intr || !imask || !rt || (s->ncams == 2 && !lr)) return set_error(CCALIB_ERR_ARG, "set_start: bad arguments");
+    if (!s || !intr || !imask || (s->ncams == 2 && !lr)) return set_error(CCALIB_ERR_ARG, "set_start: bad arguments");
+    if (!rt && !s->poses_ready[0])
+        return set_error(CCALIB_ERR_STATE, "set_start: rt is NULL and ccalib_solver_init_poses has not run for camera 0");
     HIP_TRY(hipSetDevice(s->device));
     unsigned need = 0;
     bool asp = false, rat = false;
@@ -670,13 +678,137 @@ int ccalib_solver_set_start(ccalib_solver* s, const double* intr, const unsigned
     }
     s->same_focal = same_focal != 0;
     if (lr) std::memcpy(s->lr, lr, sizeof(double) * 6);
-    HIP_TRY(hipMemcpy(s->d_pose_cur, rt, sizeof(double) * 6 * s->nviews, hipMemcpyHostToDevice));
+    if (rt) HIP_TRY(hipMemcpy(s->d_pose_cur, rt, sizeof(double) * 6 * s->nviews, hipMemcpyHostToDevice));
+    s->poses_ready[0] = s->poses_ready[1] = false;  // the LM loop takes the pose buffers over
     s->started = true;
     s->pc_fresh = false;
     s->have_cached = false;
     s->spec_valid = false;
     s->steps_since_jac = 0;
     s->prev_rejected = false;
+    return CCALIB_OK;
+}
+
+// ---- initialisation on the device -------------------------------------------------------------
+
+static InitArgs init_args(const ccalib_solver* s, int cam) {
+    InitArgs a;
+    a.img = s->d_img[cam];
+    a.obj = s->d_obj;
+    a.off = s->d_off;
+    a.nviews = s->nviews;
+    a.shared_board = s->shared_board;
+    a.board_np = s->board_np;
+    a.maxnp = s->maxnp;
+    a.PS = a.VPB = 0;
+    a.lds_bytes = 0;
+    return a;
+}
+
+// Sums n doubles over the ranks of a multi-GPU run (no-op for a single rank).
+static int allreduce_host(ccalib_solver* s, double* buf, int n) {
+    if (s->comm) {
+        HIP_TRY(hipMemcpyAsync(s->d_red, buf, sizeof(double) * n, hipMemcpyHostToDevice, s->stream));
+        NCCL_TRY(ncclAllReduce(s->d_red, s->d_red, n, ncclDouble, ncclSum, s->comm, s->stream));
+        HIP_TRY(hipMemcpyAsync(buf, s->d_red, sizeof(double) * n, hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+    } else if (s->cb) {
+        int rc = s->cb(s->cb_user, buf, n);
+        if (rc) return set_error(CCALIB_ERR_HIP, "all-reduce callback failed (%d)", rc);
+    }
+    return CCALIB_OK;
+}
+
+int ccalib_solver_init_intrinsics(ccalib_solver* s, int cam, int width, int height, double aspect, double* K) {
+    if (!s || !K || cam < 0 || cam >= s->ncams) return set_error(CCALIB_ERR_ARG, "init_intrinsics: bad arguments");
+    HIP_TRY(hipSetDevice(s->device));
+    InitArgs a = init_args(s, cam);
+    if (!init_geometry(a, false))
+        return set_error(CCALIB_ERR_UNSUPPORTED, "a view with %d points does not fit the initialisation kernels' LDS staging", s->maxnp);
+    double A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 1};
+    A[2] = !width ? 0.5 : (width - 1) * 0.5;
+    A[5] = !height ? 0.5 : (height - 1) * 0.5;
+    const int grid = (s->nviews + a.VPB - 1) / a.VPB;
+    double* d_part = nullptr;
+    HIP_TRY(hipMalloc(&d_part, sizeof(double) * 5 * grid));
+    launch_init_intrinsics(a, A[2], A[5], d_part, s->stream);
+    std::vector<double> part((size_t)5 * grid);
+    hipError_t e = hipMemcpyAsync(part.data(), d_part, sizeof(double) * part.size(), hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    (void)hipFree(d_part);
+    HIP_TRY(e);
+    double sums[5] = {0, 0, 0, 0, 0};
+    for (int b = 0; b < grid; b++)
+        for (int k = 0; k < 5; k++) sums[k] += part[(size_t)5 * b + k];
+    int rc = allreduce_host(s, sums, 5);
+    if (rc) return rc;
+    // (1/fx^2, 1/fy^2) from the 2x2 normal equations, as cvInitIntrinsicParams2D's cvSolve(DECOMP_NORMAL | DECOMP_SVD)
+    std::vector<double> N = {sums[0], sums[1], sums[1], sums[2]}, rhs = {sums[3], sums[4]};
+    solve_sym_svd(N, rhs, 2);
+    A[0] = std::sqrt(std::fabs(1. / rhs[0]));
+    A[4] = std::sqrt(std::fabs(1. / rhs[1]));
+    if (aspect != 0) {
+        double tf = (A[0] + A[4]) / (aspect + 1.);
+        A[0] = aspect * tf, A[4] = tf;
+    }
+    std::memcpy(K, A, sizeof(A));
+    return CCALIB_OK;
+}
+
+int ccalib_solver_init_poses(ccalib_solver* s, int cam, const double* K, const double* dist14, double* rt_out) {
+    if (!s || !K || cam < 0 || cam >= s->ncams) return set_error(CCALIB_ERR_ARG, "init_poses: bad arguments");
+    HIP_TRY(hipSetDevice(s->device));
+    double intr[18] = {K[0], K[4], K[2], K[5]};
+    if (dist14)
+        for (int i = 0; i < 14; i++) {
+            if (i >= 8 && dist14[i] != 0.)
+                return set_error(CCALIB_ERR_UNSUPPORTED, "thin-prism / tilted coefficients are not built into this library");
+            intr[4 + i] = dist14[i];
+        }
+    CamParams cp = cam_params(intr, 0.);
+    const bool rational = intr[9] != 0. || intr[10] != 0. || intr[11] != 0.;
+    InitArgs a = init_args(s, cam);
+    if (!init_geometry(a, true))
+        return set_error(CCALIB_ERR_UNSUPPORTED, "a view with %d points does not fit the initialisation kernels' LDS staging", s->maxnp);
+    if (!s->d_status) HIP_TRY(hipMalloc(&s->d_status, sizeof(int) * s->nviews));
+    double* dst = s->d_pose_cur;
+    if (cam == 1) {
+        if (!s->d_pose_init1) HIP_TRY(hipMalloc(&s->d_pose_init1, sizeof(double) * 6 * s->nviews));
+        dst = s->d_pose_init1;
+    }
+    launch_init_pose(a, cp, rational, dst, s->d_status, s->stream);
+    HIP_TRY(hipGetLastError());
+    std::vector<int> status(s->nviews);
+    HIP_TRY(hipMemcpyAsync(status.data(), s->d_status, sizeof(int) * s->nviews, hipMemcpyDeviceToHost, s->stream));
+    if (rt_out) HIP_TRY(hipMemcpyAsync(rt_out, dst, sizeof(double) * 6 * s->nviews, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    for (int i = 0; i < s->nviews; i++)
+        if (status[i] != 0)
+            return set_error(CCALIB_ERR_UNSUPPORTED, "view %d: pose initialisation is built for planar calibration rigs only", i);
+    s->poses_ready[cam] = true;
+    s->pc_fresh = false;
+    return CCALIB_OK;
+}
+
+int ccalib_solver_init_relative_pose(ccalib_solver* s, double* lr) {
+    if (!s || !lr || s->ncams != 2) return set_error(CCALIB_ERR_ARG, "init_relative_pose: stereo solver and an output needed");
+    if (!s->poses_ready[0] || !s->poses_ready[1])
+        return set_error(CCALIB_ERR_STATE, "init_relative_pose: ccalib_solver_init_poses must run for both cameras first");
+    HIP_TRY(hipSetDevice(s->device));
+    // six rows of npad doubles: the composition-Jacobian buffer is free until the first LM pass
+    double* d_rel = s->d_cmp[0];
+    static_assert(kCmpRows >= 6, "relative poses are staged in the composition-Jacobian buffer");
+    launch_relative_pose(s->d_pose_cur, s->d_pose_init1, s->nviews, s->npad, d_rel, s->stream);
+    std::vector<double> rel((size_t)6 * s->npad);
+    HIP_TRY(hipMemcpyAsync(rel.data(), d_rel, sizeof(double) * rel.size(), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    const int n = s->nviews;
+    for (int a = 0; a < 6; a++) {  // per-component median, as cvStereoCalibrateImpl seeds om_LR, T_LR
+        double* col = rel.data() + (size_t)a * s->npad;
+        std::nth_element(col, col + n / 2, col + n);
+        double hi = col[n / 2];
+        lr[a] = n % 2 ? hi : (*std::max_element(col, col + n / 2) + hi) * 0.5;
+    }
     return CCALIB_OK;
 }
 

@@ -166,11 +166,34 @@ void ccalib_solver_destroy(ccalib_solver* s);
  *   imask     ncams x 18 bytes, 1 = optimised (entries 12..17 must be 0)
  *   aspect    ncams doubles; non-zero ties fx = fy * aspect (CALIB_FIX_ASPECT_RATIO)
  *   same_focal   stereo only: copy fx,fy of camera 0 into camera 1 before every pass
- *   rt        nviews x 6 poses of camera 0;  lr  6 doubles (stereo; NULL for mono)
+ *   rt        nviews x 6 poses of camera 0, or NULL to start from the poses ccalib_solver_init_poses
+ *             left on the device;  lr  6 doubles (stereo; NULL for mono)
  */
 int ccalib_solver_set_start(ccalib_solver* s, const double* intr, const unsigned char* imask,
                             const double* aspect, int same_focal, const double* rt,
                             const double* lr);
+
+/*
+ * Starting values, computed on the device from the points the solver already holds: the steps OpenCV
+ * performs before its LM loop inside calibrateCamera / stereoCalibrate (monocular_circle.cpp:93-94,
+ * binocular_chessboard.cpp:147-148 and :152-162).  One lane per view.
+ *   init_intrinsics     cvInitIntrinsicParams2D / cv::initCameraMatrix2D for camera `cam`: focal
+ *                       lengths from the vanishing points of the per-view homographies, principal
+ *                       point at the image centre.  K out, 3x3.  In a multi-GPU run (after use_rccl /
+ *                       use_callback) the normal equations are summed over all ranks.
+ *   init_poses          cvFindExtrinsicCameraParams2 for every view of camera `cam` at intrinsics K
+ *                       (3x3) and distortion dist14 (14 doubles, NULL = zero): homography of the
+ *                       undistorted points, pose from it, 6-parameter LM refinement.  Camera 0's poses
+ *                       stay on the device as the starting poses (pass rt = NULL to set_start);
+ *                       rt_out (optional) receives nviews x 6 (r|t).  Planar rigs only.
+ *   init_relative_pose  stereo, after init_poses for both cameras: lr[6] = per-component median over
+ *                       this solver's views of the relative pose (om | T) of camera 1 w.r.t. camera 0.
+ */
+int ccalib_solver_init_intrinsics(ccalib_solver* s, int cam, int width, int height, double aspect,
+                                  double* K);
+int ccalib_solver_init_poses(ccalib_solver* s, int cam, const double* K, const double* dist14,
+                             double* rt_out);
+int ccalib_solver_init_relative_pose(ccalib_solver* s, double* lr);
 
 /*
  * Joins a multi-GPU run: after this call every reduction the LM loop needs (the shared normal-

@@ -1,4 +1,5 @@
 set -e
-timeout -k 10 200 python tools/stereo_bench.py 10000 20
-timeout -k 10 200 python tools/stereo_bench.py 100000 20
-CCALIB_NO_FUSED=1 CCALIB_NO_AHEAD=1 timeout -k 10 200 python tools/stereo_bench.py 100000 20
+mkdir -p gpurun_out
+timeout -k 10 500 python -u -m pytest tests/test_gpu_init.py -m gpu -q --timeout 200 --timeout-method thread > gpurun_out/t_init.log 2>&1 || { tail -60 gpurun_out/t_init.log; exit 1; }
+tail -3 gpurun_out/t_init.log
+timeout -k 10 200 python tools/wholecall_bench.py 100000
