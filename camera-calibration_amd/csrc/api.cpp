@@ -6,6 +6,9 @@
 // in the device solver (solver.hip) under the host LM driver (lm_driver.cpp).
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -18,19 +21,32 @@ using namespace ccalib;
 
 namespace {
 
+// CCALIB_TIMING=1: phase times of the whole-call entry points on stderr
+struct PhaseTimer {
+    bool on = std::getenv("CCALIB_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void lap(const char* what) {
+        if (!on) return;
+        auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[ccalib] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 struct SolverGuard {
     ccalib_solver* s = nullptr;
     ~SolverGuard() { ccalib_solver_destroy(s); }
 };
 
 bool views_share_board(int nviews, const int* npts, const float* obj) {
-    size_t ofs = npts[0];
-    for (int i = 1; i < nviews; i++) {
+    for (int i = 1; i < nviews; i++)
         if (npts[i] != npts[0]) return false;
-        if (std::memcmp(obj, obj + 3 * ofs, sizeof(float) * 3 * npts[0]) != 0) return false;
-        ofs += npts[i];
-    }
-    return true;
+    const size_t row = (size_t)3 * npts[0];
+    int differs = 0;
+#pragma omp parallel for schedule(static) reduction(| : differs)
+    for (int i = 1; i < nviews; i++)
+        if (!differs && std::memcmp(obj, obj + row * i, sizeof(float) * row) != 0) differs = 1;
+    return !differs;
 }
 
 // flag word -> 18-entry mask, exactly as cvCalibrateCamera2Internal fills CvLevMarq::mask
@@ -88,6 +104,7 @@ int ccalib_calibrate_camera(int nviews, const int* npts, const float* obj_xyz, c
         return set_error(CCALIB_ERR_ARG, "the distortion vector must have 4, 5, 8, 12 or 14 entries (got %d)", ndist);
     int rc = check_model_flags(flags);
     if (rc) return rc;
+    PhaseTimer pt;
     size_t total = 0;
     for (int i = 0; i < nviews; i++) {
         if (npts[i] < 4) return set_error(CCALIB_ERR_ARG, "view %d has %d points (at least 4 needed)", i, npts[i]);
@@ -113,8 +130,10 @@ int ccalib_calibrate_camera(int nviews, const int* npts, const float* obj_xyz, c
         for (int i = 0; i < ndist; i++) k[i] = dist[i];
     } else {
         double mean = 0, sq = 0;
+#pragma omp parallel for schedule(static) reduction(+ : mean)
         for (size_t i = 0; i < total; i++) mean += obj[3 * i + 2];
         mean /= (double)total;
+#pragma omp parallel for schedule(static) reduction(+ : sq)
         for (size_t i = 0; i < total; i++) sq += (obj[3 * i + 2] - mean) * (obj[3 * i + 2] - mean);
         if (std::fabs(mean) > 1e-5 || std::sqrt(sq / (double)total) > 1e-5)
             return set_error(CCALIB_ERR_ARG, "for non-planar calibration rigs the initial intrinsic matrix must be specified");
@@ -128,10 +147,14 @@ int ccalib_calibrate_camera(int nviews, const int* npts, const float* obj_xyz, c
     if ((flags & CCALIB_FIX_ASPECT_RATIO) && !(aspect >= 0.01 && aspect <= 100.))
         return set_error(CCALIB_ERR_ARG, "the specified aspect ratio (= cameraMatrix[0][0] / cameraMatrix[1][1]) is incorrect");
     // the points go to the device once; initialisation and the LM loop both run there
+    pt.lap("argument checks");
     bool shared = views_share_board(nviews, npts, obj);
+    pt.lap("shared-board test");
     SolverGuard g;
     if ((rc = ccalib_solver_create(&g.s, 0, 1, nviews, npts, obj, shared ? 1 : 0, img_uv, nullptr))) return rc;
+    pt.lap("solver create + upload");
     if (!(flags & CCALIB_USE_INTRINSIC_GUESS) && (rc = ccalib_solver_init_intrinsics(g.s, 0, width, height, aspect, A))) return rc;
+    pt.lap("intrinsic seed");
 
     double intr[18];
     unsigned char mask[18];
@@ -142,12 +165,14 @@ int ccalib_calibrate_camera(int nviews, const int* npts, const float* obj_xyz, c
 
     // starting poses: the caller's, or cvFindExtrinsicCameraParams2 per view (left on the device)
     if (!init_rt && (rc = ccalib_solver_init_poses(g.s, 0, A, k, nullptr))) return rc;
+    pt.lap("pose initialisation");
     std::vector<double> rt((size_t)6 * nviews);
     double asp[1] = {(flags & CCALIB_FIX_ASPECT_RATIO) ? aspect : 0.};
     if ((rc = ccalib_solver_set_start(g.s, intr, mask, asp, 0, init_rt, nullptr))) return rc;
     ccalib_stats st;
     int method = (flags & CCALIB_USE_LU) ? 0 : 1;
     if ((rc = ccalib_solver_run(g.s, term_type, max_iter, eps, method, &st))) return rc;
+    pt.lap("set_start + LM loop");
     double err = 0;
     if ((rc = ccalib_solver_get(g.s, intr, rt.data(), nullptr, &err))) return rc;
     K[0] = intr[0], K[1] = 0, K[2] = intr[2], K[3] = 0, K[4] = intr[1], K[5] = intr[3], K[6] = 0, K[7] = 0, K[8] = 1;
@@ -158,6 +183,7 @@ int ccalib_calibrate_camera(int nviews, const int* npts, const float* obj_xyz, c
     }
     *rms = std::sqrt(err / (double)total);
     if (stats) *stats = st;
+    pt.lap("download");
     return CCALIB_OK;
 }
 

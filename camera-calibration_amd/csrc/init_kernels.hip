@@ -491,7 +491,7 @@ __device__ __forceinline__ float2 undistort(float2 m, const CamParams& cp) {
 
 // ---- cvFindExtrinsicCameraParams2 for every view ---------------------------------------------
 template <bool RAT>
-__global__ __launch_bounds__(64) void k_init_pose(InitArgs a, CamParams cp, double* __restrict__ pose, int* __restrict__ status) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_init_pose(InitArgs a, CamParams cp, double* __restrict__ pose, int* __restrict__ status) {
     using M = Model<0u, false, RAT>;
     const int lane = threadIdx.x;
     const int v0 = blockIdx.x * a.VPB;

@@ -108,7 +108,11 @@ struct ccalib_solver {
     std::vector<double> spec_U, spec_gs, spec_S;
     double spec_err = 0, spec_lambda = 0;
     int steps_since_jac = 0;
-    bool prev_rejected = false;
+    // Whether the last trial step taken at each damping level (10^-16 .. 10^16) was accepted: a step is run
+    // ahead only at a level whose last trial was accepted, which follows the accept/reject pattern an LM
+    // run settles into (e.g. every first trial at 1e-3 rejected, every retry at 1e-2 accepted).
+    bool level_accepted[33];
+    int last_level = 0;
 
     // multi-GPU
     ncclComm_t comm = nullptr;
@@ -353,7 +357,7 @@ int be_jac(void* user, const double* shared, double lambda_hint, double* U, doub
     ccalib_solver* s = (ccalib_solver*)user;
     s->t_enter = std::chrono::steady_clock::now();
     const int ns = s->ns();
-    s->prev_rejected = s->steps_since_jac > 1;
+    if (s->steps_since_jac > 0) s->level_accepted[s->last_level] = true;  // the driver moved on: that step was accepted
     s->steps_since_jac = 0;
     if (s->spec_valid && std::memcmp(shared, s->spec_shared, sizeof(double) * ns) == 0) {
         // this pass was run ahead by the step that produced the point: adopt its buffer and sums
@@ -442,7 +446,9 @@ int be_step_err(void* user, double lambda, double lambda_next, const int* fidx, 
     }
     if ((rc = queue_colsum(s, npart, s->nblk64, 2, 0))) return rc;
     store_shared(s, shared_new);
-    const bool ahead = s->speculate && s->steps_since_jac == 0 && !s->prev_rejected;
+    if (s->steps_since_jac > 0) s->level_accepted[s->last_level] = false;  // a retry: the step before was rejected
+    s->last_level = std::min(32, std::max(0, (int)std::lround(std::log10(lambda)) + 16));
+    const bool ahead = s->speculate && s->level_accepted[s->last_level];
     s->steps_since_jac++;
     s->spec_valid = false;
     s->have_cached = false;
@@ -685,7 +691,7 @@ int ccalib_solver_set_start(ccalib_solver* s, const double* intr, const unsigned
     s->have_cached = false;
     s->spec_valid = false;
     s->steps_since_jac = 0;
-    s->prev_rejected = false;
+    for (bool& b : s->level_accepted) b = true;
     return CCALIB_OK;
 }
 

@@ -12,7 +12,7 @@ import sys
 
 def short(name):
     name = re.sub(r"^void\s+", "", name)
-    name = name.replace("ccalib::", "")
+    name = name.replace("(anonymous namespace)::", "").replace("ccalib::", "")
     return re.sub(r"\(.*$", "", name)
 
 

@@ -14,10 +14,18 @@ def main():
     synth = pkg.synth
     obj = synth.chessboard(9, 6, 25.0)
     ms = synth.make_views(obj, views, 0xC0FFEE + 4)
-    for rep in range(2):
+    import ctypes as C
+    lib = pkg.capi.load()
+    N, npts, o, img = pkg._flatten(obj, ms.img)        # the caller's buffers: vector<vector<Point3f/2f>> flattened
+    for rep in range(3):
+        A, d, rv, tv = np.eye(3).reshape(-1), np.zeros(5), np.zeros((N, 3)), np.zeros((N, 3))
+        rms, st = C.c_double(), pkg.capi.Stats()
         t0 = time.perf_counter()
-        got = pkg.calibrate_camera(obj, ms.img, (640, 480), criteria=(3, 30, 2.2e-16))
+        pkg.capi.check(lib.ccalib_calibrate_camera(
+            C.c_int(N), pkg._p(npts), pkg._p(o), pkg._p(img), C.c_int(640), C.c_int(480), pkg._p(A), pkg._p(d), C.c_int(5),
+            pkg._p(rv), pkg._p(tv), C.c_int(0), C.c_int(3), C.c_int(30), C.c_double(2.2e-16), None, C.byref(rms), C.byref(st)))
         dt = time.perf_counter() - t0
+        got = dict(device_ms=st.device_ms, iters=st.iters, rms=rms.value)
     print(json.dumps({"views": views, "whole_call_s": round(dt, 4), "lm_loop_ms": round(got["device_ms"], 3), "iters": got["iters"],
                       "rms": got["rms"]}))
 
