@@ -311,6 +311,38 @@ __device__ __forceinline__ void lanes_reduce_store(const double (&acc)[N], doubl
     });
 }
 
+// The same reduction for values produced one at a time (so that they need not all be live at once):
+// push() parks the value in LDS, and every 32 values lanes 0..31 add up one value's 64 contributions
+// each, in a fixed order, and store them to consecutive slots of out.  All indices are compile-time
+// constants once the calling loops are unrolled.  sm: 32 * 65 doubles.
+struct LaneReducer {
+    double* sm;
+    double* out;
+    int k = 0, base = 0;
+    __device__ __forceinline__ LaneReducer(double* sm_, double* out_) : sm(sm_), out(out_) {}
+    __device__ __forceinline__ void push(double v) {
+        sm[k * 65 + (threadIdx.x & 63)] = v;
+        if (++k == 32) flush();
+    }
+    __device__ __forceinline__ void flush() {
+        if (k == 0) return;
+        const int lane = threadIdx.x & 63;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < k) {
+            double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+            for (int j = 0; j < 64; j += 4) {
+                s0 += sm[lane * 65 + j], s1 += sm[lane * 65 + j + 1];
+                s2 += sm[lane * 65 + j + 2], s3 += sm[lane * 65 + j + 3];
+            }
+            out[base + lane] = (s0 + s1) + (s2 + s3);
+        }
+        __builtin_amdgcn_wave_barrier();
+        base += k;
+        k = 0;
+    }
+};
+
 // In-place lower Cholesky of a symmetric 6x6 given by its upper triangle packed row-major
 // (21 values: (0,0) (0,1) .. (0,5) (1,1) ..).  On return L[i][j] (j <= i) and the reciprocal
 // diagonal.  Returns false when the matrix is not positive definite.

@@ -196,16 +196,12 @@ __global__ __launch_bounds__(64) void k_stereo_lr_sums(const double* blk1, const
 #pragma unroll
     for (int a = 0; a < 6; a++) row_times_B(c, V3[a], N[a]);  // V3 B
     Bt_times(c, N, BtN);
-    double* out = part + (size_t)blockIdx.x * NOUT;
-    int k = 0;
+    __shared__ double sm[32 * 65];
+    LaneReducer red(sm, part + (size_t)blockIdx.x * NOUT);
 #pragma unroll
     for (int a = 0; a < 6; a++)
 #pragma unroll
-        for (int b = a; b < 6; b++) {
-            double s = wave_sum(live ? BtN[a][b] : 0.);
-            if (threadIdx.x == 0) out[k] = s;
-            k++;
-        }
+        for (int b = a; b < 6; b++) red.push(live ? BtN[a][b] : 0.);
     double g[6];
     // B^T ge3
 #pragma unroll
@@ -215,11 +211,7 @@ __global__ __launch_bounds__(64) void k_stereo_lr_sums(const double* blk1, const
         g[3 + a] = ge3[3 + a];
     }
 #pragma unroll
-    for (int a = 0; a < 6; a++) {
-        double s = wave_sum(live ? g[a] : 0.);
-        if (threadIdx.x == 0) out[k] = s;
-        k++;
-    }
+    for (int a = 0; a < 6; a++) red.push(live ? g[a] : 0.);
 #pragma unroll
     for (int i = 0; i < NC1; i++) {
         double w[6], wb[6];
@@ -227,12 +219,9 @@ __global__ __launch_bounds__(64) void k_stereo_lr_sums(const double* blk1, const
         for (int b = 0; b < 6; b++) w[b] = blk1[blk_index((27 + 6 * NC1), 27 + 6 * i + b, vv)];
         row_times_B(c, w, wb);
 #pragma unroll
-        for (int b = 0; b < 6; b++) {
-            double s = wave_sum(live ? wb[b] : 0.);
-            if (threadIdx.x == 0) out[k] = s;
-            k++;
-        }
+        for (int b = 0; b < 6; b++) red.push(live ? wb[b] : 0.);
     }
+    red.flush();
 }
 
 // Assembles the stereo view block: V (packed upper, damped later), ge, and M = V3 A (kept for W_LR).
@@ -305,8 +294,8 @@ __global__ __launch_bounds__(64) void k_stereo_schur(const double* blk0, const d
         row_times_A(c, w, Z[6 + NC0 + i]);
         chol6_fwd(L, invd, Z[6 + NC0 + i]);
     }
-    double* out = part + (size_t)blockIdx.x * NS;
-    int k = 0;
+    __shared__ double sm[32 * 65];
+    LaneReducer red(sm, part + (size_t)blockIdx.x * NS);
 #pragma unroll
     for (int i = 0; i < KC; i++)
 #pragma unroll
@@ -314,19 +303,16 @@ __global__ __launch_bounds__(64) void k_stereo_schur(const double* blk0, const d
             double d = 0;
 #pragma unroll
             for (int b = 0; b < 6; b++) d += Z[i][b] * Z[j][b];
-            d = wave_sum(ok ? d : 0.);
-            if (threadIdx.x == 0) out[k] = d;
-            k++;
+            red.push(ok ? d : 0.);
         }
 #pragma unroll
     for (int i = 0; i < KC; i++) {
         double d = 0;
 #pragma unroll
         for (int b = 0; b < 6; b++) d += Z[i][b] * y[b];
-        d = wave_sum(ok ? d : 0.);
-        if (threadIdx.x == 0) out[k] = d;
-        k++;
+        red.push(ok ? d : 0.);
     }
+    red.flush();
 }
 
 template <int NC0, int NC1>
