@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libccalib.so")
+LIB_PATH = os.environ.get("CCALIB_LIB") or os.path.join(_HERE, "libccalib.so")   # CCALIB_LIB: a development build
 
 # every symbol include/ccalib.h declares
 SYMBOLS = [

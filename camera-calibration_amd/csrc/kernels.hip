@@ -33,6 +33,9 @@ namespace ccalib {
 
 static constexpr int kBlock = 256;
 static constexpr int kWaves = kBlock / 64;
+#ifndef CCALIB_EXP
+#define CCALIB_EXP 0   // development experiments on the fused kernel (see k_jac_fused); 0 = product
+#endif
 #ifndef CCALIB_VIEW_MINWAVES
 #define CCALIB_VIEW_MINWAVES 1  // wavefronts per SIMD the per-view-block kernel is compiled for
 #endif
@@ -389,6 +392,10 @@ __global__ __launch_bounds__(kBlock, 3) void k_jac_fused(PassArgs a, CamParams c
     double* const ldsd = reinterpret_cast<double*>(lds_dyn);  // indexed, so every access stays an LDS access
     const int cbase = board_f / 2;                             // the two shared columns (in doubles)
     const int jt = cbase + (CONSTC ? 2 * RS : 0) + w * NPRIV * RS;  // this wavefront's buffer
+    // after the four column buffers: one 16-double slot per wavefront through which a view's pose record
+    // reaches all lanes (a dword per lane in, broadcast reads out: no vector-ALU instruction involved,
+    // which matters because nothing else issues on a SIMD while an FP64 MFMA executes)
+    const int pslot = cbase + (CONSTC ? 2 * RS : 0) + kWaves * NPRIV * RS + w * kPoseConstStride;
     auto slot = [&](int c) { return CONSTC && c > ICY ? c - 2 : c; };  // private column -> position in the buffer
     if constexpr (CONSTC) {
         for (int r = threadIdx.x; r < RS; r += kBlock) {
@@ -428,9 +435,10 @@ __global__ __launch_bounds__(kBlock, 3) void k_jac_fused(PassArgs a, CamParams c
     // What the wavefront needs to start on a view -- point range, this lane's image point, the pose --
     // is fetched one view ahead, between the point phase and the matrix phase of the view before,
     // so that its latency hides under the MFMAs.  The pose record (26 dwords) is fetched with ONE
-    // dword load, lane k taking dword k, and spread to scalar registers with v_readlane when the view
-    // starts: a broadcast vector load of the record would cost 16 L1 cycles per 16 bytes, and scalar
-    // loads share their wait counter with the LDS reads of the matrix phase.
+    // dword load, lane k taking dword k, and handed to all lanes through the wavefront's LDS slot after
+    // the matrix phase (spread_pose): a broadcast vector load of the record would cost 16 L1 cycles per
+    // 16 bytes, scalar loads share their wait counter with the LDS reads of the matrix phase, and
+    // v_readlane costs a vector-ALU slot per dword.
     int first = 0, np = 0;
     float2 mpt = make_float2(0.f, 0.f);
     float bX = 0.f, bY = 0.f, bZ = 0.f;  // this lane's object point of the first chunk
@@ -476,20 +484,35 @@ __global__ __launch_bounds__(kBlock, 3) void k_jac_fused(PassArgs a, CamParams c
     int npsum = 0;                     // points this wavefront has seen
     // Point phase of one chunk of at most CH points: lane p < n evaluates its point and writes its two
     // rows of A; rows of an earlier, longer chunk are cleared.
+    double qd[14];  // the current view's pose record, the same in every lane
+    auto spread_pose = [&]() {
+        unsigned* const slotw = reinterpret_cast<unsigned*>(lds_dyn) + 2 * pslot;
+        if (lane < 32) slotw[lane] = qword;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            double2 t = lds2r[(pslot >> 1) + k];
+            qd[2 * k] = t.x, qd[2 * k + 1] = t.y;
+        }
+    };
     auto point_phase = [&](int n, float2 m, float X, float Y, float Z) {
         if (lane < n) {
-            double qd[13];
-#pragma unroll
-            for (int k = 0; k < 13; k++) {
-                unsigned lo = __builtin_amdgcn_readlane(qword, 2 * k), hi = __builtin_amdgcn_readlane(qword, 2 * k + 1);
-                qd[k] = __hiloint2double((int)hi, (int)lo);
-            }
             PoseConst q;
             q.ax[0] = qd[0], q.ax[1] = qd[1], q.ax[2] = qd[2], q.c = qd[3], q.c1 = qd[4], q.s = qd[5];
             q.b1 = qd[6], q.b2 = qd[7], q.b3 = qd[8], q.b4 = qd[9], q.t[0] = qd[10], q.t[1] = qd[11], q.t[2] = qd[12];
             PointOut<M> o;
             double jex[6], jey[6];
+#if CCALIB_EXP == 2 || CCALIB_EXP == 3   // experiment: no per-point arithmetic
+            for (int k = 0; k < NC; k++) o.jx[k] = q.ax[0] + m.x, o.jy[k] = q.c + m.y;
+            for (int k = 0; k < 6; k++) jex[k] = q.t[0] + X, jey[k] = q.t[1] + Y;
+            o.ex = m.x, o.ey = Z;
+#else
             point_jacobian<M>(q, cp, (double)X, (double)Y, (double)Z, (double)m.x, (double)m.y, o, jex, jey);
+#endif
+#if CCALIB_EXP == 3   // experiment: and no LDS writes either
+            if (o.ex == 12345.678) lds2[dst] = make_double2(jex[0] + o.jx[3], jey[1]);
+            return;
+#endif
             static_for<0, NC>([&](auto ic_) {
                 constexpr int i = decltype(ic_)::value;
                 if constexpr (!(CONSTC && (i == ICX || i == ICY)))
@@ -507,27 +530,43 @@ __global__ __launch_bounds__(kBlock, 3) void k_jac_fused(PassArgs a, CamParams c
         }
         dirty = n;
     };
-    // Matrix phase: sixteen rows per trip (this lane feeds rows 8m + 2rq and 8m + 2rq + 1 of column
-    // `col` in step m), the two operand pairs in alternating registers (no copies); the read of the step
-    // after is in flight while a step multiplies.  CH is a multiple of 8, so the rows up to the next
-    // multiple of 16 exist and are zero.
-    auto matrix_phase = [&](int n, double4_t& acc) {
+    // Matrix phase: sixteen rows per trip.  A 16-byte LDS read gives a lane rows 8k + 2rq and 8k + 2rq + 1
+    // of column `col`, the operands of two MFMAs; the two reads of the trip after are in flight while a
+    // trip multiplies, at a fixed distance (they may run past the chunk's rows: what they fetch is then
+    // never used).  The only vector-ALU instruction of a trip is the address increment -- any other would
+    // take the SIMD away from the matrix pipe, since nothing else issues while an FP64 MFMA executes.
+    // CH is a multiple of 8, so the rows up to the next multiple of 16 exist and are zero.
+    auto matrix_phase = [&](int n, double4_t& acc, bool from_zero) {
+#if CCALIB_EXP == 1   // experiment: no matrix phase
+        acc[0] += lds2r[src].x;
+        return;
+#endif
         __builtin_amdgcn_wave_barrier();
-        const int npairs = (2 * n + 15) >> 4;
-        const int last = src + 8 * (npairs - 1) + 4;
-        int nxt = src + 4;
-        double2 pa = lds2r[src];
-        for (int k = 0; k < npairs; k++) {
-            double2 pb = lds2r[nxt];
-            nxt = nxt + 4 < last ? nxt + 4 : last;
+        const int ntrips = (2 * n + 15) >> 4;  // >= 1
+        auto mfma4 = [&](const double2& u0, const double2& u1) {
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(u0.x, u0.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(u0.y, u0.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(u1.x, u1.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(u1.y, u1.y, acc, 0, 0, 0);
+        };
+        // two register sets take turns (no copies); the first trip starts the chain from zero
+        int a = src + 8;
+        double2 p0 = lds2r[src], p1 = lds2r[src + 4];
+        double2 q0 = lds2r[a], q1 = lds2r[a + 4];
+        __builtin_amdgcn_sched_barrier(0);
+        if (from_zero) acc = double4_t{0., 0., 0., 0.};  // the chain's first link then takes a literal zero
+        mfma4(p0, p1);
+        for (int k = 1; k < ntrips;) {
+            a += 8;
+            p0 = lds2r[a], p1 = lds2r[a + 4];
             __builtin_amdgcn_sched_barrier(0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.x, pa.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.y, pa.y, acc, 0, 0, 0);
-            pa = lds2r[nxt];
-            nxt = nxt + 4 < last ? nxt + 4 : last;
+            mfma4(q0, q1);
+            if (++k >= ntrips) break;
+            a += 8;
+            q0 = lds2r[a], q1 = lds2r[a + 4];
             __builtin_amdgcn_sched_barrier(0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pb.x, pb.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pb.y, pb.y, acc, 0, 0, 0);
+            mfma4(p0, p1);
+            ++k;
         }
         __builtin_amdgcn_wave_barrier();  // the reads are done before the buffer is overwritten
     };
@@ -537,6 +576,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_jac_fused(PassArgs a, CamParams c
         valid = tile < ntiles && v < a.nviews;
         if (valid) fetch(v);
     };
+    if (valid) spread_pose();
     while (valid) {
         const int tile_cur = tile, vfirst = first, vnp = np;
         npsum += vnp;
@@ -544,7 +584,8 @@ __global__ __launch_bounds__(kBlock, 3) void k_jac_fused(PassArgs a, CamParams c
         if constexpr (!MULTI) {  // the launcher guarantees np <= CH <= 64
             point_phase(vnp, mpt, bX, bY, bZ);
             advance();
-            matrix_phase(vnp, acc);
+            matrix_phase(vnp, acc, true);
+            if (valid) spread_pose();
         } else {
             for (int p0 = 0; p0 < vnp; p0 += CH) {
                 const int n = vnp - p0 < CH ? vnp - p0 : CH;
@@ -560,8 +601,10 @@ __global__ __launch_bounds__(kBlock, 3) void k_jac_fused(PassArgs a, CamParams c
                     }
                 }
                 point_phase(n, m, X, Y, Z);
-                if (p0 + CH >= vnp) advance();
-                matrix_phase(n, acc);
+                const bool last = p0 + CH >= vnp;
+                if (last) advance();
+                matrix_phase(n, acc, p0 == 0);
+                if (last && valid) spread_pose();
             }
         }
         usum += acc;
@@ -854,8 +897,10 @@ FusedGeom fused_geom(int maxnp, bool shared_board, int board_np, bool const_cols
     g.RS = 2 * g.CH;
     while (!(g.RS % 32 == 2 || g.RS % 32 == 14 || g.RS % 32 == 18 || g.RS % 32 == 30)) g.RS += 2;
     size_t board_f = shared_board ? (size_t)(3 * board_np + 3) / 4 * 4 : 0;
-    // 14 private columns per wavefront + 2 shared ones when the principal point is in the set, else 16
-    g.lds_bytes = (unsigned)(sizeof(float) * board_f + sizeof(double) * (const_cols ? kWaves * 14 + 2 : kWaves * 16) * (size_t)g.RS);
+    // 14 private columns per wavefront + 2 shared ones when the principal point is in the set, else 16;
+    // then one pose-record slot per wavefront
+    g.lds_bytes = (unsigned)(sizeof(float) * board_f + sizeof(double) * (const_cols ? kWaves * 14 + 2 : kWaves * 16) * (size_t)g.RS +
+                             sizeof(double) * kWaves * kPoseConstStride);
     return g;
 }
 
