@@ -33,9 +33,6 @@ namespace ccalib {
 
 static constexpr int kBlock = 256;
 static constexpr int kWaves = kBlock / 64;
-#ifndef CCALIB_EXP
-#define CCALIB_EXP 0   // development experiments on the fused kernel (see k_jac_fused); 0 = product
-#endif
 #ifndef CCALIB_VIEW_MINWAVES
 #define CCALIB_VIEW_MINWAVES 1  // wavefronts per SIMD the per-view-block kernel is compiled for
 #endif
@@ -502,17 +499,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_jac_fused(PassArgs a, CamParams c
             q.b1 = qd[6], q.b2 = qd[7], q.b3 = qd[8], q.b4 = qd[9], q.t[0] = qd[10], q.t[1] = qd[11], q.t[2] = qd[12];
             PointOut<M> o;
             double jex[6], jey[6];
-#if CCALIB_EXP == 2 || CCALIB_EXP == 3   // experiment: no per-point arithmetic
-            for (int k = 0; k < NC; k++) o.jx[k] = q.ax[0] + m.x, o.jy[k] = q.c + m.y;
-            for (int k = 0; k < 6; k++) jex[k] = q.t[0] + X, jey[k] = q.t[1] + Y;
-            o.ex = m.x, o.ey = Z;
-#else
             point_jacobian<M>(q, cp, (double)X, (double)Y, (double)Z, (double)m.x, (double)m.y, o, jex, jey);
-#endif
-#if CCALIB_EXP == 3   // experiment: and no LDS writes either
-            if (o.ex == 12345.678) lds2[dst] = make_double2(jex[0] + o.jx[3], jey[1]);
-            return;
-#endif
             static_for<0, NC>([&](auto ic_) {
                 constexpr int i = decltype(ic_)::value;
                 if constexpr (!(CONSTC && (i == ICX || i == ICY)))
@@ -537,10 +524,6 @@ __global__ __launch_bounds__(kBlock, 3) void k_jac_fused(PassArgs a, CamParams c
     // take the SIMD away from the matrix pipe, since nothing else issues while an FP64 MFMA executes.
     // CH is a multiple of 8, so the rows up to the next multiple of 16 exist and are zero.
     auto matrix_phase = [&](int n, double4_t& acc, bool from_zero) {
-#if CCALIB_EXP == 1   // experiment: no matrix phase
-        acc[0] += lds2r[src].x;
-        return;
-#endif
         __builtin_amdgcn_wave_barrier();
         const int ntrips = (2 * n + 15) >> 4;  // >= 1
         auto mfma4 = [&](const double2& u0, const double2& u1) {
