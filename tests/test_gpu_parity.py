@@ -192,6 +192,33 @@ def test_stereo_full_distortion_small_dense(pkg, orc, synth):
     assert np.allclose(got["d1"][:5], ref["d1"][:5], rtol=1e-5, atol=1e-8)
 
 
+def test_config5_shape_17x12_board_stereo_and_mono(pkg, orc, synth):
+    """BASELINE config 5's shape at a size the dense oracle solves: 17x12 board (204 points per view, so
+    every view spans four 64-point chunks of the fused kernel), both cameras with k1-k3, p1, p2 free."""
+    obj = synth.chessboard(17, 12, 10.0)
+    st = synth.make_stereo(obj, 16, 0xC0FFEE + 5)
+    K1 = pkg.init_camera_matrix_2d(obj, st.img1, (640, 480))
+    K2 = pkg.init_camera_matrix_2d(obj, st.img2, (640, 480))
+    assert np.allclose(K1, orc.init_camera_matrix_2d(obj, st.img1, (640, 480)), rtol=1e-8)
+    crit = (3, 60, 1e-7)
+    got = pkg.stereo_calibrate(obj, st.img1, st.img2, K1, None, K2, None, (640, 480), pkg.CALIB_USE_INTRINSIC_GUESS,
+                               criteria=crit)
+    ref = orc.stereo_calibrate(obj, st.img1, st.img2, K1, None, K2, None, (640, 480), orc.USE_INTRINSIC_GUESS,
+                               criteria=crit, schur=False)
+    assert abs(got["rms"] - ref["rms"]) <= REL * ref["rms"]
+    assert abs(got["iters"] - ref["iters"]) <= 1
+    for key in ("K1", "K2", "R", "T", "E", "F"):
+        assert np.allclose(got[key], ref[key], rtol=REL, atol=1e-8 * np.abs(ref[key]).max()), key
+    assert np.allclose(got["d1"][:5], ref["d1"][:5], rtol=1e-5, atol=1e-8)
+    assert np.abs(got["rt"] - ref["rt"])[:, :3].max() < 1e-6
+    # one camera of it through calibrateCamera (initialisation included)
+    crit = (3, 30, 1e-9)
+    gm = pkg.calibrate_camera(obj, st.img1, (640, 480), criteria=crit)
+    rm = orc.calibrate_camera(obj, st.img1, (640, 480), criteria=crit, schur=False)
+    _close_params(gm, rm)
+    assert abs(gm["iters"] - rm["iters"]) <= 1
+
+
 def test_reprojection_error_matches_oracle(pkg, orc, synth):
     obj = synth.chessboard(9, 6, 25.0)
     ms = synth.make_views(obj, 50, 3)
