@@ -198,14 +198,15 @@ class Solver:
         capi.check(self._lib.ccalib_solver_num_shared(self._h, C.byref(n)))
         return n.value
 
-    def set_start(self, intr, imask, rt, aspect=None, same_focal=False, lr=None):
+    def set_start(self, intr, imask, rt, aspect=None, same_focal=False, lr=None, fix_intrinsic=False):
         intr = np.ascontiguousarray(intr, dtype=np.float64).reshape(self.ncams, 18)
         imask = np.ascontiguousarray(imask, dtype=np.uint8).reshape(self.ncams, 18)
         asp = np.zeros(self.ncams) if aspect is None else np.ascontiguousarray(aspect, dtype=np.float64).reshape(self.ncams)
         rt = None if rt is None else np.ascontiguousarray(rt, dtype=np.float64).reshape(self.nviews, 6)
         lrp = None if lr is None else np.ascontiguousarray(lr, dtype=np.float64).reshape(6)
         capi.check(self._lib.ccalib_solver_set_start(self._h, _p(intr), _p(imask), _p(asp),
-                                                     C.c_int(1 if same_focal else 0), _p(rt), _p(lrp)))
+                                                     C.c_int((1 if same_focal else 0) | (2 if fix_intrinsic else 0)),
+                                                     _p(rt), _p(lrp)))
 
     def init_intrinsics(self, size, cam=0, aspect=0.0):
         """cv::initCameraMatrix2D on the device for camera `cam` (summed over ranks in a sharded run)."""

@@ -196,8 +196,6 @@ int ccalib_stereo_calibrate(int nviews, const int* npts, const float* obj_xyz, c
         return set_error(CCALIB_ERR_ARG, "stereoCalibrate: null argument");
     int rc = check_model_flags(flags);
     if (rc) return rc;
-    if (flags & CCALIB_FIX_INTRINSIC)
-        return set_error(CCALIB_ERR_UNSUPPORTED, "CALIB_FIX_INTRINSIC is not built into this library yet");
     size_t total = 0;
     for (int i = 0; i < nviews; i++) {
         if (npts[i] < 4) return set_error(CCALIB_ERR_ARG, "view %d has %d points (at least 4 needed)", i, npts[i]);
@@ -208,12 +206,12 @@ int ccalib_stereo_calibrate(int nviews, const int* npts, const float* obj_xyz, c
     double* dio[2] = {dist1, dist2};
     double Ak[2][9] = {{0}}, dk[2][14] = {{0}};
     for (int c = 0; c < 2; c++) {
-        if (flags & (CCALIB_USE_INTRINSIC_GUESS | CCALIB_FIX_ASPECT_RATIO | CCALIB_FIX_FOCAL_LENGTH))
+        if (flags & (CCALIB_FIX_INTRINSIC | CCALIB_USE_INTRINSIC_GUESS | CCALIB_FIX_ASPECT_RATIO | CCALIB_FIX_FOCAL_LENGTH))
             std::memcpy(Ak[c], Kio[c], sizeof(Ak[c]));
-        if (flags & (CCALIB_USE_INTRINSIC_GUESS | CCALIB_FIX_K1 | CCALIB_FIX_K2 | CCALIB_FIX_K3 | CCALIB_FIX_K4 |
+        if (flags & (CCALIB_FIX_INTRINSIC | CCALIB_USE_INTRINSIC_GUESS | CCALIB_FIX_K1 | CCALIB_FIX_K2 | CCALIB_FIX_K3 | CCALIB_FIX_K4 |
                      CCALIB_FIX_K5 | CCALIB_FIX_K6 | CCALIB_FIX_TANGENT_DIST))
             std::memcpy(dk[c], dio[c], sizeof(dk[c]));
-        if (!(flags & CCALIB_USE_INTRINSIC_GUESS)) {
+        if (!(flags & (CCALIB_FIX_INTRINSIC | CCALIB_USE_INTRINSIC_GUESS))) {
             // OpenCV calibrates each camera on its own first
             std::vector<double> rv((size_t)3 * nviews), tv((size_t)3 * nviews);
             double r0;
@@ -252,6 +250,7 @@ int ccalib_stereo_calibrate(int nviews, const int* npts, const float* obj_xyz, c
             if (f & CCALIB_FIX_K6) m[11] = 0;
             for (int q = 12; q < 18; q++) m[q] = 0;
         }
+        if (flags & CCALIB_FIX_INTRINSIC) std::memset(mask, 0, 36);  // intrinsics are not parameters at all
     }
     bool shared = views_share_board(nviews, npts, obj_xyz);
     SolverGuard g;
@@ -273,8 +272,10 @@ int ccalib_stereo_calibrate(int nviews, const int* npts, const float* obj_xyz, c
         ip[0] = Ak[c][0], ip[1] = Ak[c][4], ip[2] = Ak[c][2], ip[3] = Ak[c][5];
         std::memcpy(ip + 4, dk[c], sizeof(dk[c]));
     }
-    if ((rc = ccalib_solver_set_start(g.s, intr, mask, aspect, (flags & CCALIB_SAME_FOCAL_LENGTH) ? 1 : 0,
-                                      given ? init_rt : nullptr, lr)))
+    const bool fixed = (flags & CCALIB_FIX_INTRINSIC) != 0;
+    if (fixed) aspect[0] = aspect[1] = 0;  // no ties to enforce between fixed values
+    const int opts = fixed ? CCALIB_STEREO_FIX_INTRINSIC : (flags & CCALIB_SAME_FOCAL_LENGTH) ? CCALIB_STEREO_SAME_FOCAL_LENGTH : 0;
+    if ((rc = ccalib_solver_set_start(g.s, intr, mask, aspect, opts, given ? init_rt : nullptr, lr)))
         return rc;
     ccalib_stats st;
     int method = (flags & CCALIB_USE_LU) ? 0 : 1;

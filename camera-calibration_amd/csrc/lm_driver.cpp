@@ -11,6 +11,8 @@
 #include <chrono>
 #include <cfloat>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -131,6 +133,16 @@ extern "C" int ccalib_lm_run(const ccalib_backend* be, void* user, double* share
     const double LOG10 = std::log(10.);
     auto lam = [&](int lg) { return std::exp(lg * LOG10); };
 
+    // CCALIB_TRACE=<file>: one JSON line per LM iteration (damping, residual sum, trial steps, host time)
+    std::FILE* trace = nullptr;
+    if (const char* tp = std::getenv("CCALIB_TRACE")) trace = std::fopen(tp, "a");
+    struct TraceClose {
+        std::FILE* f;
+        ~TraceClose() {
+            if (f) std::fclose(f);
+        }
+    } trace_close{trace};
+
     std::vector<int> fidx;
     for (int i = 0; i < ns; i++)
         if (smask[i]) fidx.push_back(i);
@@ -179,12 +191,22 @@ extern "C" int ccalib_lm_run(const ccalib_backend* be, void* user, double* share
         prev.assign(shared, shared + ns);
         if ((rc = be->commit(user))) return rc;
         prevErrNorm = errNorm;
+        const auto ti = std::chrono::steady_clock::now();
+        const int lambda_first = lambdaLg10;
+        int trials = 1;
         if ((rc = step_and_eval(errNorm))) return rc;
         // CHECK_ERR
         while (errNorm > prevErrNorm) {  // a NaN compares false and is accepted, as in CvLevMarq
             if (++lambdaLg10 > 16) break;
+            trials++;
             if ((rc = step_and_eval(errNorm))) return rc;
         }
+        if (trace)
+            std::fprintf(trace,
+                         "{\"iter\": %d, \"lambda_lg10_first\": %d, \"lambda_lg10_accepted\": %d, \"trials\": %d, "
+                         "\"err_prev\": %.17g, \"err\": %.17g, \"step_norm2\": %.17g, \"ms\": %.4f}\n",
+                         iters, lambda_first, std::min(lambdaLg10, 16), trials, prevErrNorm, errNorm, dn2,
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ti).count());
         lambdaLg10 = std::max(lambdaLg10 - 1, -16);
         double num = dn2, den = pn2;
         for (int i = 0; i < ns; i++) {

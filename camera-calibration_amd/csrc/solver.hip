@@ -90,6 +90,7 @@ struct ccalib_solver {
     unsigned char imask[2][18];
     double aspect[2] = {0, 0};
     bool same_focal = false;
+    bool fix_intrinsic = false;  // stereo, CALIB_FIX_INTRINSIC: the parameter vector holds om_LR, T_LR and the poses only
     double lr[6] = {0, 0, 0, 0, 0, 0};
     StereoLR lr_jac[2];  // relative pose the per-view blocks of each buffer were computed at
     const ModelOps* ops[2] = {nullptr, nullptr};
@@ -119,7 +120,7 @@ struct ccalib_solver {
     ccalib_allreduce_fn cb = nullptr;
     void* cb_user = nullptr;
 
-    int ns() const { return ncams == 1 ? 18 : 42; }
+    int ns() const { return ncams == 1 ? 18 : fix_intrinsic ? 6 : 42; }
     int kcols() const { return ncams == 1 ? ops[0]->NC : 6 + ops[0]->NC + ops[1]->NC; }
     // kernel column -> index in the shared vector
     int kcol_to_shared(int k) const {
@@ -230,6 +231,7 @@ void current_shared(const ccalib_solver* s, double* shared) {
         std::memcpy(shared, s->intr[0], sizeof(double) * 18);
     } else {
         std::memcpy(shared, s->lr, sizeof(double) * 6);
+        if (s->fix_intrinsic) return;
         std::memcpy(shared + 6, s->intr[0], sizeof(double) * 18);
         std::memcpy(shared + 24, s->intr[1], sizeof(double) * 18);
     }
@@ -239,6 +241,7 @@ void store_shared(ccalib_solver* s, const double* shared) {
         std::memcpy(s->intr[0], shared, sizeof(double) * 18);
     } else {
         std::memcpy(s->lr, shared, sizeof(double) * 6);
+        if (s->fix_intrinsic) return;
         std::memcpy(s->intr[0], shared + 6, sizeof(double) * 18);
         std::memcpy(s->intr[1], shared + 24, sizeof(double) * 18);
     }
@@ -334,6 +337,10 @@ void parse_jac(const ccalib_solver* s, const JacLayout& L, double* U, double* gs
         const double* r = s->h_red + L.cam_ofs[c];
         int base = s->ncams == 1 ? 0 : 6 + 18 * c;
         int k = 0;
+        if (s->fix_intrinsic) {  // the intrinsic columns are not parameters: only the residual sum is kept
+            e += r[m->NRED_U - 1];
+            continue;
+        }
         for (int i = 0; i < m->NC; i++)
             for (int j = i; j < m->NC; j++) U[(size_t)(base + m->col(i)) * ns + base + m->col(j)] = r[k++];
         for (int i = 0; i < m->NC; i++) gs[base + m->col(i)] = r[k++];
@@ -346,8 +353,9 @@ void parse_jac(const ccalib_solver* s, const JacLayout& L, double* U, double* gs
             for (int j = i; j < 6; j++) U[(size_t)i * ns + j] = r[k++];
         for (int i = 0; i < 6; i++) gs[i] = r[k++];
         const ModelOps* m1 = s->ops[1];
-        for (int i = 0; i < m1->NC; i++)
-            for (int b = 0; b < 6; b++) U[(size_t)b * ns + 24 + m1->col(i)] = r[k++];
+        if (!s->fix_intrinsic)
+            for (int i = 0; i < m1->NC; i++)
+                for (int b = 0; b < 6; b++) U[(size_t)b * ns + 24 + m1->col(i)] = r[k++];
     }
     *err = e;
     S.assign(s->h_red + L.schur_ofs, s->h_red + L.schur_ofs + L.nsum);
@@ -400,7 +408,8 @@ int be_reduce(void* user, double lambda, const int* fidx, int nf, double* Ssum, 
     }
     // kernel-column space -> the driver's free set
     std::vector<int> s2k(s->ns(), -1);
-    for (int k = 0; k < kc; k++) s2k[s->kcol_to_shared(k)] = k;
+    for (int k = 0; k < kc; k++)
+        if (s->kcol_to_shared(k) < s->ns()) s2k[s->kcol_to_shared(k)] = k;
     auto tri = [kc](int a, int b) { return a * kc - a * (a - 1) / 2 + (b - a); };
     for (int a = 0; a < nf; a++) {
         int ka = s2k[fidx[a]];
@@ -439,7 +448,8 @@ int be_step_err(void* user, double lambda, double lambda_next, const int* fidx, 
     } else {
         StereoDelta sd;
         int kc = s->kcols();
-        for (int k = 0; k < kStereoMaxCols; k++) sd.v[k] = k < kc ? dfull[s->kcol_to_shared(k)] : 0.;
+        for (int k = 0; k < kStereoMaxCols; k++)
+            sd.v[k] = k < kc && s->kcol_to_shared(k) < s->ns() ? dfull[s->kcol_to_shared(k)] : 0.;
         if (!launch_stereo_backsub(s->ops[0]->NC, s->d_blk[0][cur], s->d_blk[1][cur], s->d_cmp[cur], s->lr_jac[cur],
                                    s->npad, s->nviews, lambda, sd, s->d_pose_prev, s->d_pose_cur, npart, s->stream))
             return set_error(CCALIB_ERR_UNSUPPORTED, "stereo column count %d is not built in", s->ops[0]->NC);
@@ -499,6 +509,7 @@ void be_fixup(void* user, double* shared, double* prev) {
         }
         return;
     }
+    if (s->fix_intrinsic) return;
     double* ip = shared + 6;
     double* pp = prev + 6;
     if (s->same_focal) {
@@ -638,7 +649,7 @@ void ccalib_solver_destroy(ccalib_solver* s) {
 }
 
 int ccalib_solver_set_start(ccalib_solver* s, const double* intr, const unsigned char* imask, const double* aspect,
-                            int same_focal, const double* rt, const double* lr) {
+                            int stereo_opts, const double* rt, const double* lr) {
     if (!s || !intr || !imask || (s->ncams == 2 && !lr)) return set_error(CCALIB_ERR_ARG, "set_start: bad arguments");
     if (!rt && !s->poses_ready[0])
         return set_error(CCALIB_ERR_STATE, "set_start: rt is NULL and ccalib_solver_init_poses has not run for camera 0");
@@ -682,7 +693,11 @@ int ccalib_solver_set_start(ccalib_solver* s, const double* intr, const unsigned
         s->part_used = 0;
         s->segs.nseg = 0;
     }
-    s->same_focal = same_focal != 0;
+    s->same_focal = (stereo_opts & CCALIB_STEREO_SAME_FOCAL_LENGTH) != 0;
+    s->fix_intrinsic = s->ncams == 2 && (stereo_opts & CCALIB_STEREO_FIX_INTRINSIC) != 0;
+    if (s->fix_intrinsic)
+        for (int q = 0; q < 36; q++)
+            if (imask[q]) return set_error(CCALIB_ERR_ARG, "CCALIB_STEREO_FIX_INTRINSIC needs every intrinsic masked out");
     if (lr) std::memcpy(s->lr, lr, sizeof(double) * 6);
     if (rt) HIP_TRY(hipMemcpy(s->d_pose_cur, rt, sizeof(double) * 6 * s->nviews, hipMemcpyHostToDevice));
     s->poses_ready[0] = s->poses_ready[1] = false;  // the LM loop takes the pose buffers over
@@ -856,8 +871,10 @@ int ccalib_solver_run(ccalib_solver* s, int term_type, int max_iter, double eps,
         std::memcpy(smask, s->imask[0], 18);
     else {
         std::memset(smask, 1, 6);
-        std::memcpy(smask + 6, s->imask[0], 18);
-        std::memcpy(smask + 24, s->imask[1], 18);
+        if (!s->fix_intrinsic) {
+            std::memcpy(smask + 6, s->imask[0], 18);
+            std::memcpy(smask + 24, s->imask[1], 18);
+        }
     }
     s->t_wait = s->t_enqueue = 0;
     int rc = ccalib_lm_run(&be, s, shared, smask, term_type, max_iter, eps, solve_method, stats);

@@ -165,12 +165,16 @@ void ccalib_solver_destroy(ccalib_solver* s);
  *   intr      ncams x 18 doubles: fx fy cx cy k1 k2 p1 p2 k3 k4 k5 k6 s1 s2 s3 s4 taux tauy
  *   imask     ncams x 18 bytes, 1 = optimised (entries 12..17 must be 0)
  *   aspect    ncams doubles; non-zero ties fx = fy * aspect (CALIB_FIX_ASPECT_RATIO)
- *   same_focal   stereo only: copy fx,fy of camera 0 into camera 1 before every pass
+ *   stereo_opts  stereo only, bits: CCALIB_STEREO_SAME_FOCAL_LENGTH copies fx,fy of camera 0 into camera 1
+ *             before every pass; CCALIB_STEREO_FIX_INTRINSIC (every imask entry 0) takes the intrinsics out of
+ *             the parameter vector altogether, as cv::stereoCalibrate does under CALIB_FIX_INTRINSIC: the
+ *             convergence norm then runs over om_LR, T_LR and the poses only
  *   rt        nviews x 6 poses of camera 0, or NULL to start from the poses ccalib_solver_init_poses
  *             left on the device;  lr  6 doubles (stereo; NULL for mono)
  */
+enum { CCALIB_STEREO_SAME_FOCAL_LENGTH = 1, CCALIB_STEREO_FIX_INTRINSIC = 2 };
 int ccalib_solver_set_start(ccalib_solver* s, const double* intr, const unsigned char* imask,
-                            const double* aspect, int same_focal, const double* rt,
+                            const double* aspect, int stereo_opts, const double* rt,
                             const double* lr);
 
 /*

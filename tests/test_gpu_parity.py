@@ -192,6 +192,27 @@ def test_stereo_full_distortion_small_dense(pkg, orc, synth):
     assert np.allclose(got["d1"][:5], ref["d1"][:5], rtol=1e-5, atol=1e-8)
 
 
+def test_stereo_fix_intrinsic_default_flag(pkg, orc, synth):
+    """cv::stereoCalibrate's default flag word, CALIB_FIX_INTRINSIC: only om_LR, T_LR and the poses move, and the
+    convergence norm runs over those alone (the intrinsics are not in the parameter vector)."""
+    obj = synth.chessboard(9, 6, 25.0)
+    st = synth.make_stereo(obj, 60, 0xC0FFEE + 6)
+    m1 = pkg.calibrate_camera(obj, st.img1, (640, 480))
+    m2 = pkg.calibrate_camera(obj, st.img2, (640, 480))
+    for crit in ((3, 100, 1e-6), (3, 100, 1e-9)):
+        got = pkg.stereo_calibrate(obj, st.img1, st.img2, m1["K"], m1["dist"], m2["K"], m2["dist"], (640, 480),
+                                   pkg.CALIB_FIX_INTRINSIC, criteria=crit)
+        ref = orc.stereo_calibrate(obj, st.img1, st.img2, m1["K"], m1["dist"], m2["K"], m2["dist"], (640, 480),
+                                   pkg.CALIB_FIX_INTRINSIC, criteria=crit, schur=False)
+        assert abs(got["rms"] - ref["rms"]) <= REL * ref["rms"]
+        assert abs(got["iters"] - ref["iters"]) <= 1
+        assert np.array_equal(got["K1"], m1["K"]) and np.array_equal(got["d2"][:5], m2["dist"])   # untouched
+        for key in ("R", "T", "E", "F"):
+            assert np.allclose(got[key], ref[key], rtol=REL, atol=1e-8 * np.abs(ref[key]).max()), key
+        assert np.abs(got["rt"] - ref["rt"])[:, :3].max() < 1e-6
+    assert np.allclose(got["T"], [-60.0, 0.5, 1.0], atol=0.5)
+
+
 def test_config5_shape_17x12_board_stereo_and_mono(pkg, orc, synth):
     """BASELINE config 5's shape at a size the dense oracle solves: 17x12 board (204 points per view, so
     every view spans four 64-point chunks of the fused kernel), both cameras with k1-k3, p1, p2 free."""

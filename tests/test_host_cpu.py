@@ -90,6 +90,27 @@ def test_lm_driver_matches_oracle_state_machine(pkg, orc, synth, flags_name):
     assert be.calls["commit"] == st["iters"]
 
 
+def test_lm_trace_one_json_line_per_iteration(pkg, orc, synth, tmp_path, monkeypatch):
+    """CCALIB_TRACE=<file>: the driver appends one JSON record per LM iteration (damping exponent tried
+    first and accepted, number of trial steps, residual sums before and after)."""
+    import json
+    from tests.cpu_backend import OracleBackend, run_lm
+    obj = synth.chessboard(9, 6, 25.0)
+    ms = synth.make_views(obj, 8, 3)
+    cam = ms.cam
+    K0 = np.array([[cam.fx * 0.97, 0, cam.cx + 3], [0, cam.fy * 0.97, cam.cy - 2], [0, 0, 1.0]])
+    intr, mask, aspect = pkg.mono_start(K0, cam.dist(5) * 0.8, 0)
+    rt0 = synth.perturbed_poses(ms.rvec, ms.tvec, 3, rot_sigma=0.01, trans_sigma=3.0)
+    path = tmp_path / "trace.jsonl"
+    monkeypatch.setenv("CCALIB_TRACE", str(path))
+    _, _, st = run_lm(pkg, OracleBackend(pkg, orc, obj, ms.img, rt0, mask, aspect), intr, (3, 6, 0.0))
+    recs = [json.loads(ln) for ln in path.read_text().splitlines()]
+    assert [r["iter"] for r in recs] == list(range(st["iters"])) and st["iters"] == 6
+    assert sum(r["trials"] for r in recs) == st["err_passes"]
+    assert all(r["err"] <= r["err_prev"] for r in recs) and recs[-1]["err"] == st["final_err"]
+    assert recs[0]["lambda_lg10_first"] == -3
+
+
 def test_sharded_lm_over_two_gloo_ranks():
     """world_size 2 on CPU: each rank owns half the views, every sum goes through gloo all_reduce."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
