@@ -1,2 +1,3 @@
 set -e
-timeout -k 10 500 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread 2>&1 | tail -30
+timeout -k 10 400 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err
+cat gpurun_out/bench.json
