@@ -173,11 +173,10 @@ def main():
         }
         cpu = None
         whole = None
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:   # the CPU leg and the whole-call leg are timed at N = 1 only
             cpu = cpu_baseline(ge, synth, obj, args.cpu_views, seed, pkg)
             cpu["opencv"] = opencv_check(pkg, synth)
-            if world == 1:
-                whole = whole_call(pkg, obj, ms)
+            whole = whole_call(pkg, obj, ms)
         result = {
             "metric": "residual+Jacobian point evaluations/s in the calibrateCamera LM loop (100k views/GPU, 9x6 board)",
             "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
