@@ -92,9 +92,50 @@ void eig_sym(std::vector<double> A, int n, std::vector<double>& w, std::vector<d
     }
 }
 
-// cv::solve DECOMP_SVD on a symmetric matrix: eigen back-substitution, dropping
+// cv::solve DECOMP_SVD on a symmetric matrix.
+// The SVD solution of a symmetric positive definite system that is not numerically singular is its
+// ordinary solution, so that case -- every reduced system of a healthy calibration -- is solved by a
+// Cholesky factorisation (0.5 us for 9x9 against 12 us for the eigen decomposition, which sits on the
+// critical path of every LM iteration while the GPU waits).  Like Jacobi rotations, Cholesky is accurate
+// relative to the diagonally scaled matrix, which matters here: the columns of the reduced system differ by
+// many orders of magnitude (focal lengths against k3).  Whenever a pivot falls below 1e-10 of its diagonal
+// entry or below 1e4 times SVD's own cut-off (2 eps sum|w| = 2 eps trace) -- the matrix may then be rank
+// deficient for SVD's purposes -- the eigen path decides: eigen back-substitution, dropping
 // |w| <= 2 eps sum|w| as SVD back-substitution does.
 void solve_sym_svd(const std::vector<double>& A, std::vector<double>& b, int n) {
+    if (n <= 64) {
+        double L[64 * 64], y[64], trace = 0;
+        for (int i = 0; i < n; i++) trace += std::fabs(A[i * n + i]);
+        const double cut = 1e4 * 2 * DBL_EPSILON * trace;
+        bool ok = true;
+        for (int i = 0; i < n && ok; i++) {
+            for (int j = 0; j <= i; j++) {
+                double sum = A[i * n + j];
+                for (int k = 0; k < j; k++) sum -= L[i * n + k] * L[j * n + k];
+                if (i == j) {
+                    if (!(sum > 1e-10 * A[i * n + i]) || !(sum > cut)) {
+                        ok = false;
+                        break;
+                    }
+                    L[i * n + i] = std::sqrt(sum);
+                } else
+                    L[i * n + j] = sum / L[j * n + j];
+            }
+        }
+        if (ok) {
+            for (int i = 0; i < n; i++) {
+                double sum = b[i];
+                for (int k = 0; k < i; k++) sum -= L[i * n + k] * y[k];
+                y[i] = sum / L[i * n + i];
+            }
+            for (int i = n - 1; i >= 0; i--) {
+                double sum = y[i];
+                for (int k = i + 1; k < n; k++) sum -= L[k * n + i] * b[k];
+                b[i] = sum / L[i * n + i];
+            }
+            return;
+        }
+    }
     std::vector<double> w, V, x(n, 0.);
     eig_sym(A, n, w, V);
     double thr = 0;

@@ -1,5 +1,4 @@
 set -e
-export TMPDIR=/tmp
-rm -rf gpurun_out/prof_stereo
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stereo -o st -- python3 tools/stereo_bench.py 100000 20 > gpurun_out/stereo_prof.log 2>&1
-tail -1 gpurun_out/stereo_prof.log
+timeout -k 10 200 python bench.py --no-cpu | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['rms_px'])"
+timeout -k 10 200 python tools/stereo_bench.py 100000 20
+timeout -k 10 500 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread 2>&1 | tail -3
