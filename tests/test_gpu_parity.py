@@ -153,6 +153,52 @@ def test_intrinsic_guess_and_fixed_subsets(pkg, orc, synth):
         assert np.abs(got["rvecs"] - ref["rvecs"]).max() < 10 * tol
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_random_flag_subsets_match_oracle(pkg, orc, synth, seed):
+    """Flag words drawn at random from the CALIB_* bits the library accepts (every mask the flag -> mask mapping of
+    cvCalibrateCamera2Internal can produce for the 12-coefficient model), with an intrinsic guess."""
+    rng = np.random.default_rng(1000 + seed)
+    obj = synth.chessboard(9, 6, 25.0)
+    ms = synth.make_views(obj, 18, 50 + seed)
+    cam = ms.cam
+    optional = [pkg.CALIB_FIX_ASPECT_RATIO, pkg.CALIB_FIX_PRINCIPAL_POINT, pkg.CALIB_ZERO_TANGENT_DIST, pkg.CALIB_FIX_K1,
+                pkg.CALIB_FIX_K2, pkg.CALIB_FIX_K3, pkg.CALIB_FIX_FOCAL_LENGTH, pkg.CALIB_FIX_TANGENT_DIST, pkg.CALIB_USE_LU]
+    flags = pkg.CALIB_USE_INTRINSIC_GUESS
+    for f in optional:
+        if rng.random() < 0.35:
+            flags |= f
+    nd = 5
+    if rng.random() < 0.4:   # rational model with a random subset of k4..k6 held
+        flags |= pkg.CALIB_RATIONAL_MODEL
+        nd = 8
+        for f in (pkg.CALIB_FIX_K4, pkg.CALIB_FIX_K5, pkg.CALIB_FIX_K6):
+            if rng.random() < 0.6:
+                flags |= f
+    K0 = np.array([[cam.fx * 1.02, 0, cam.cx - 2], [0, cam.fy * 1.02, cam.cy + 3], [0, 0, 1.0]])
+    d0 = np.zeros(nd)
+    d0[:5] = cam.dist(5) * 0.9
+    crit = (3, 25, 1e-8)
+    got = pkg.calibrate_camera(obj, ms.img, (640, 480), K=K0, dist=d0, ndist=nd, flags=flags, criteria=crit)
+    ref = orc.calibrate_camera(obj, ms.img, (640, 480), K=K0, dist=d0, ndist=nd, flags=flags, criteria=crit, schur=False)
+    free_rational = nd == 8 and not all(flags & f for f in (pkg.CALIB_FIX_K4, pkg.CALIB_FIX_K5, pkg.CALIB_FIX_K6))
+    tol = 2e-5 if free_rational else 1e-6      # numerator and denominator polynomials nearly cancel on this data
+    assert abs(got["rms"] - ref["rms"]) <= 1e-6 * ref["rms"], hex(flags)
+    assert abs(got["iters"] - ref["iters"]) <= 1, hex(flags)
+    assert np.allclose(got["K"], ref["K"], rtol=tol, atol=1e-9), hex(flags)
+    assert np.abs(got["rvecs"] - ref["rvecs"]).max() < 10 * tol, hex(flags)
+    if not free_rational:
+        assert np.allclose(got["dist"], ref["dist"], rtol=1e-5, atol=1e-8), hex(flags)
+    # held parameters come back exactly as given
+    if flags & pkg.CALIB_FIX_PRINCIPAL_POINT:
+        assert got["K"][0, 2] == K0[0, 2] and got["K"][1, 2] == K0[1, 2]
+    if flags & pkg.CALIB_FIX_FOCAL_LENGTH:
+        assert got["K"][1, 1] == K0[1, 1]
+    if flags & pkg.CALIB_FIX_K2:
+        assert got["dist"][1] == d0[1]
+    if flags & pkg.CALIB_ZERO_TANGENT_DIST:
+        assert got["dist"][2] == 0 and got["dist"][3] == 0
+
+
 def test_config3_stereo_reference_flags(pkg, orc, synth):
     """BASELINE config 3 at reduced N: the flag set of binocular_chessboard.cpp:156-161, criteria (100, 1e-5)."""
     obj = synth.chessboard(9, 6, 25.0)
