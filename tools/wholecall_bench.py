@@ -30,5 +30,27 @@ def main():
                       "rms": got["rms"]}))
 
 
+def stereo():
+    """python tools/wholecall_bench.py stereo [pairs]: cv::stereoCalibrate's whole call with the reference's flag
+    set (BASELINE config 3: 10 000 pairs), initCameraMatrix2D for both cameras included."""
+    pairs = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000
+    pkg = ge.load_package()
+    synth = pkg.synth
+    obj = synth.chessboard(9, 6, 25.0)
+    st = synth.make_stereo(obj, pairs, 0xC0FFEE + 3)
+    flags = (pkg.CALIB_FIX_ASPECT_RATIO | pkg.CALIB_ZERO_TANGENT_DIST | pkg.CALIB_USE_INTRINSIC_GUESS |
+             pkg.CALIB_SAME_FOCAL_LENGTH | pkg.CALIB_RATIONAL_MODEL | pkg.CALIB_FIX_K3 | pkg.CALIB_FIX_K4 |
+             pkg.CALIB_FIX_K5)
+    for rep in range(3):
+        t0 = time.perf_counter()
+        K1 = pkg.init_camera_matrix_2d(obj, st.img1, (640, 480))
+        K2 = pkg.init_camera_matrix_2d(obj, st.img2, (640, 480))
+        t1 = time.perf_counter()
+        got = pkg.stereo_calibrate(obj, st.img1, st.img2, K1, None, K2, None, (640, 480), flags, criteria=(3, 100, 1e-5))
+        t2 = time.perf_counter()
+    print(json.dumps({"pairs": pairs, "init_camera_matrix_s": round(t1 - t0, 4), "stereo_calibrate_s": round(t2 - t1, 4),
+                      "lm_loop_ms": round(got["device_ms"], 3), "iters": got["iters"], "rms": got["rms"]}))
+
+
 if __name__ == "__main__":
-    main()
+    stereo() if len(sys.argv) > 1 and sys.argv[1] == "stereo" else main()
