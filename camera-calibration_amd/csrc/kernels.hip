@@ -136,12 +136,23 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[N], double* red
 }
 
 // Walks the points g, g+G, ... of one staged view; body(X, Y, Z, u, v) is called once per point.
-// `local` is the view's first point relative to the stage.
-template <int G, class Body>
+// `local` is the view's first point relative to the stage.  Two points are in flight per trip: a point's
+// arithmetic is one long dependent chain (a division in the middle), and with the few wavefronts per SIMD the
+// stage leaves room for, a second independent chain is what keeps the FP64 pipe issuing.
+// (PAIR; the Jacobian kernels, whose accumulators already fill the register file, take one point at a time.)
+template <int G, bool PAIR = false, class Body>
 __device__ __forceinline__ void for_points(const PassArgs& a, const Lane<G>& l, int local, int np, Body&& body) {
     const float* obj = a.shared_board ? l.board : l.sobj + 3 * local;
     const float2* img = l.simg + local;
-    for (int p = l.g; p < np; p += G) {
+    int p = l.g;
+    for (; PAIR && p + G < np; p += 2 * G) {
+        float2 m0 = img[p], m1 = img[p + G];
+        float X0 = obj[3 * p], Y0 = obj[3 * p + 1], Z0 = obj[3 * p + 2];
+        float X1 = obj[3 * (p + G)], Y1 = obj[3 * (p + G) + 1], Z1 = obj[3 * (p + G) + 2];
+        body((double)X0, (double)Y0, (double)Z0, (double)m0.x, (double)m0.y);
+        body((double)X1, (double)Y1, (double)Z1, (double)m1.x, (double)m1.y);
+    }
+    for (; p < np; p += G) {
         float2 m = img[p];
         float X = obj[3 * p], Y = obj[3 * p + 1], Z = obj[3 * p + 2];
         body((double)X, (double)Y, (double)Z, (double)m.x, (double)m.y);
@@ -161,7 +172,7 @@ __global__ __launch_bounds__(kBlock) void k_err(PassArgs a, CamParams cp, double
         int base = stage_views(a, l);
         double R[9];
         rodrigues<false>(h.ps, R, nullptr);
-        for_points<G>(a, l, h.first - base, h.np, [&](double X, double Y, double Z, double u, double v) {
+        for_points<G, true>(a, l, h.first - base, h.np, [&](double X, double Y, double Z, double u, double v) {
             double Xc = R[0] * X + R[1] * Y + R[2] * Z + h.ps[3];
             double Yc = R[3] * X + R[4] * Y + R[5] * Z + h.ps[4];
             double Zc = R[6] * X + R[7] * Y + R[8] * Z + h.ps[5];
