@@ -56,6 +56,9 @@ struct Lane {
     float2* simg;  // this wavefront's stage
     float* sobj;
     const float* board;
+    int base;      // global index of the first point of the current round (set by stage_views)
+    bool staged;   // false: views too long for the stage -- points are read from global memory, which with all
+                   // 64 lanes on one view (the only G such views get) is one contiguous run per load anyway
     __device__ __forceinline__ Lane(const PassArgs& a) {
         lane = threadIdx.x & 63;
         g = lane & (G - 1);
@@ -69,6 +72,8 @@ struct Lane {
         simg = reinterpret_cast<float2*>(p + w * per_wave);
         sobj = p + w * per_wave + 2 * S;
         board = lds_dyn;
+        base = 0;
+        staged = a.staged != 0;
     }
     __device__ __forceinline__ void next_round() {
         v0 += stride;
@@ -86,10 +91,12 @@ __device__ __forceinline__ void stage_board(const PassArgs& a) {
 // Copies the points of views [v0, v0 + VPW) into the wavefront's stage; returns the global index of
 // the first staged point.  Only lanes of this wavefront touch the stage, so a wave barrier orders it.
 template <int G>
-__device__ __forceinline__ int stage_views(const PassArgs& a, const Lane<G>& l) {
+__device__ __forceinline__ int stage_views(const PassArgs& a, Lane<G>& l) {
     int vA = l.v0 < a.nviews ? l.v0 : a.nviews;
     int vB = l.v0 + Lane<G>::VPW < a.nviews ? l.v0 + Lane<G>::VPW : a.nviews;
     int base = a.off[vA], n = a.off[vB] - base;
+    l.base = base;
+    if (!l.staged) return base;
     __builtin_amdgcn_wave_barrier();  // the previous round's reads are done before the stage is overwritten
     for (int i = l.lane; i < n; i += 64) l.simg[i] = a.img[base + i];
     if (!a.shared_board) {
@@ -142,8 +149,8 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[N], double* red
 // (PAIR; the Jacobian kernels, whose accumulators already fill the register file, take one point at a time.)
 template <int G, bool PAIR = false, class Body>
 __device__ __forceinline__ void for_points(const PassArgs& a, const Lane<G>& l, int local, int np, Body&& body) {
-    const float* obj = a.shared_board ? l.board : l.sobj + 3 * local;
-    const float2* img = l.simg + local;
+    const float* obj = a.shared_board ? l.board : l.staged ? l.sobj + 3 * local : a.obj + 3 * (size_t)(l.base + local);
+    const float2* img = l.staged ? l.simg + local : a.img + (l.base + local);
     int p = l.g;
     for (; PAIR && p + G < np; p += 2 * G) {
         float2 m0 = img[p], m1 = img[p + G];

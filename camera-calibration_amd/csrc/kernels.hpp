@@ -16,6 +16,7 @@ struct PassArgs {
     int board_np;
     int maxnp;           // largest point count of any view
     int G;               // lanes per view (power of two, 2..64)
+    int staged;          // 1: the per-point kernels copy each round's points to LDS first; 0: they read global memory
     unsigned lds_bytes;  // dynamic LDS per workgroup, from pass_lds_bytes()
 };
 

@@ -48,6 +48,7 @@ struct ccalib_solver {
     bool shared_board = false;
     int board_np = 0;
     int G = 4, nblk64 = 0, npad = 0;
+    bool staged = true;  // per-point kernels stage a round's points in LDS (false: views too long for that)
     int grid_view = 0;  // per-view kernels: every wavefront does one round
     int grid_red = 0;   // reducing kernels: fewer workgroups, several rounds each, one reduction at the end
     int grid_fused = 0; // fused Jacobian kernel: workgroups striding over tiles of kTileViews views
@@ -154,6 +155,7 @@ PassArgs pass_args(const ccalib_solver* s, int cam, const double* pose) {
     a.maxnp = s->maxnp;
     a.lds_bytes = s->lds_bytes;
     a.G = s->G;
+    a.staged = s->staged ? 1 : 0;
     return a;
 }
 
@@ -583,12 +585,13 @@ int ccalib_solver_create(ccalib_solver** out, int device, int ncams, int nviews,
     }
     s->board_np = shared_board ? npts[0] : 0;
     s->G = choose_G(nviews, s->maxnp, s->shared_board, s->board_np);
-    if (!s->G) {
-        int mp = s->maxnp;
-        delete s;
-        return set_error(CCALIB_ERR_UNSUPPORTED, "a view with %d points does not fit the kernels' LDS staging", mp);
+    if (s->G) {
+        s->lds_bytes = (unsigned)pass_lds_bytes(s->G, s->maxnp, s->shared_board, s->board_np);
+    } else {  // not even one view per wavefront fits the stage: all 64 lanes on a view, points straight from HBM
+        s->G = 64;
+        s->staged = false;
+        s->lds_bytes = (unsigned)(sizeof(float) * (s->shared_board ? 3 * (size_t)s->board_np : 0));
     }
-    s->lds_bytes = (unsigned)pass_lds_bytes(s->G, s->maxnp, s->shared_board, s->board_np);
     int views_per_block = pass_block_size() / s->G;
     s->grid_view = (nviews + views_per_block - 1) / views_per_block;
     s->grid_red = std::min(s->grid_view, 512);

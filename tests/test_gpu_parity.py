@@ -286,6 +286,29 @@ def test_config5_shape_17x12_board_stereo_and_mono(pkg, orc, synth):
     assert abs(gm["iters"] - rm["iters"]) <= 1
 
 
+def test_extreme_shapes_one_view_and_a_1200_point_board(pkg, orc, synth):
+    """Smallest and largest shapes the kernels take: a single view (one lane of one wavefront carries the whole
+    elimination), three views (less than one tile of four), and a 40x30 board whose 1200 points per view exceed
+    what the shared-board LDS copy holds (the board is then replicated per view and walked in 19 chunks)."""
+    obj = synth.chessboard(9, 6, 25.0)
+    crit = (3, 30, 1e-9)
+    for n in (1, 3):
+        ms = synth.make_views(obj, n, 900 + n)
+        K0 = ms.cam.K() * np.array([[1.01, 1, 1], [1, 1.01, 1], [1, 1, 1]])
+        flags = pkg.CALIB_USE_INTRINSIC_GUESS | pkg.CALIB_FIX_K3 | pkg.CALIB_ZERO_TANGENT_DIST
+        got = pkg.calibrate_camera(obj, ms.img, (640, 480), K=K0, dist=np.zeros(5), flags=flags, criteria=crit)
+        ref = orc.calibrate_camera(obj, ms.img, (640, 480), K=K0, dist=np.zeros(5), flags=flags, criteria=crit, schur=False)
+        assert abs(got["rms"] - ref["rms"]) <= 1e-6 * ref["rms"]
+        assert np.allclose(got["K"], ref["K"], rtol=1e-5)          # one to three views determine the camera poorly
+        assert abs(got["iters"] - ref["iters"]) <= 1
+    big = synth.chessboard(40, 30, 4.0)
+    ms = synth.make_views(big, 5, 77)
+    got = pkg.calibrate_camera(big, ms.img, (640, 480), criteria=crit)
+    ref = orc.calibrate_camera(big, ms.img, (640, 480), criteria=crit, schur=False)
+    _close_params(got, ref)
+    assert abs(got["iters"] - ref["iters"]) <= 1
+
+
 def test_reprojection_error_matches_oracle(pkg, orc, synth):
     obj = synth.chessboard(9, 6, 25.0)
     ms = synth.make_views(obj, 50, 3)

@@ -1,5 +1,2 @@
 set -e
-timeout -k 10 120 python tools/kernel_bench.py 100000 200
-CCALIB_NO_FUSED=1 timeout -k 10 120 python tools/kernel_bench.py 100000 200
-timeout -k 10 200 python tools/stereo_bench.py 100000 20
-timeout -k 10 500 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread 2>&1 | tail -3
+timeout -k 10 500 python -u -m pytest tests/test_gpu_parity.py -m gpu -q --timeout 300 --timeout-method thread -k "extreme" 2>&1 | tail -40
