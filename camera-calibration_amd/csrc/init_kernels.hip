@@ -27,6 +27,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "device_math.hpp"
 
 namespace ccalib {
@@ -452,21 +455,26 @@ __device__ __forceinline__ Stage stage_layout(const InitArgs& a, bool with_src) 
     s.img = s.src + nsrc;
     return s;
 }
-// copies the image points of views [v0, v0 + nv) to the stage (every lane of the wavefront takes part)
-__device__ __forceinline__ void stage_img(const InitArgs& a, const Stage& s, int v0, int nv) {
+// copies the image points of the workgroup's nv views (view_of(j), j < nv) to the stage; every lane of the
+// wavefront takes part
+template <class ViewOf>
+__device__ __forceinline__ void stage_img(const InitArgs& a, const Stage& s, ViewOf view_of, int nv) {
     const int lane = threadIdx.x;
     for (int j = 0; j < nv; j++) {
-        int first = a.off[v0 + j], n = a.off[v0 + j + 1] - first;
+        int v = view_of(j);
+        int first = a.off[v], n = a.off[v + 1] - first;
         for (int p = lane; p < n; p += 64) s.img[j * s.PS + p] = a.img[first + p];
     }
 }
-__device__ __forceinline__ void stage_obj(const InitArgs& a, const Stage& s, int v0, int nv) {
+template <class ViewOf>
+__device__ __forceinline__ void stage_obj(const InitArgs& a, const Stage& s, ViewOf view_of, int nv) {
     const int lane = threadIdx.x;
     if (a.shared_board) {
         for (int i = lane; i < 3 * a.board_np; i += 64) s.obj[i] = a.obj[i];
     } else {
         for (int j = 0; j < nv; j++) {
-            int first = a.off[v0 + j], n = a.off[v0 + j + 1] - first;
+            int v = view_of(j);
+            int first = a.off[v], n = a.off[v + 1] - first;
             for (int i = lane; i < 3 * n; i += 64) s.obj[j * 3 * s.PS + i] = a.obj[3 * (size_t)first + i];
         }
     }
@@ -489,9 +497,90 @@ __device__ __forceinline__ float2 undistort(float2 m, const CamParams& cp) {
 
 }  // namespace
 
+// CvLevMarq(6 parameters) with criteria (COUNT + EPS, 20, FLT_EPSILON) on the reprojection error of one view:
+// the refinement at the end of cvFindExtrinsicCameraParams2.  Most views are done after five iterations, one
+// in a hundred needs all twenty, and a wavefront runs as long as its slowest lane: so the loop can be left
+// at an iteration boundary (stop_at) with its state -- pose, damping exponent, iteration count, residual norm --
+// and picked up later by a wavefront filled with such views only (fresh = false).  Returns true when done.
+template <class M, class Obj>
+__device__ bool refine_pose(int n, Obj obj, const float2* irow, const CamParams& cp, double (&ps)[6], int& lambdaLg10,
+                            int& iters, double& errNorm, bool fresh, int stop_at) {
+    double JtJ[21], Jte[6], prev[6];
+    auto eval_err = [&]() {
+        double R[9], e2 = 0;
+        rodrigues<false>(ps, R, nullptr);
+        for (int p = 0; p < n; p++) {
+            float3 o = obj(p);
+            float2 m = irow[p];
+            double X = o.x, Y = o.y, Z = o.z;
+            double Xc = R[0] * X + R[1] * Y + R[2] * Z + ps[3];
+            double Yc = R[3] * X + R[4] * Y + R[5] * Z + ps[4];
+            double Zc = R[6] * X + R[7] * Y + R[8] * Z + ps[5];
+            PointOut<M> o2;
+            point_eval<M, false, false>(Xc, Yc, Zc, (double)m.x, (double)m.y, cp, o2);
+            e2 += o2.ex * o2.ex + o2.ey * o2.ey;
+        }
+        return e2;
+    };
+    auto eval_jac = [&]() {
+        const PoseConst q = pose_const(ps);
+        double e2 = 0;
+#pragma unroll
+        for (int k = 0; k < 21; k++) JtJ[k] = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) Jte[k] = 0;
+        for (int p = 0; p < n; p++) {
+            float3 o = obj(p);
+            float2 m = irow[p];
+            PointOut<M> o2;
+            double jex[6], jey[6];
+            point_jacobian<M>(q, cp, (double)o.x, (double)o.y, (double)o.z, (double)m.x, (double)m.y, o2, jex, jey);
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+#pragma unroll
+                for (int j = i; j < 6; j++) JtJ[tri6(i, j)] += jex[i] * jex[j] + jey[i] * jey[j];
+                Jte[i] += jex[i] * o2.ex + jey[i] * o2.ey;
+            }
+            e2 += o2.ex * o2.ex + o2.ey * o2.ey;
+        }
+        return e2;
+    };
+    auto step = [&]() {
+        double lambda = exp(lambdaLg10 * 2.302585092994046);
+        double L[21], invd[6], x[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) x[k] = Jte[k];
+        bool pd = chol6(JtJ, lambda, L, invd);
+        chol6_fwd(L, invd, x);
+        chol6_bwd(L, invd, x);
+#pragma unroll
+        for (int k = 0; k < 6; k++) ps[k] = prev[k] - (pd ? x[k] : 0.);
+    };
+    double e0 = sqrt(eval_jac());
+    double prevErrNorm = fresh ? e0 : errNorm;  // resumed: the norm the loop was left with (the same point)
+    for (;;) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) prev[k] = ps[k];
+        step();
+        errNorm = sqrt(eval_err());
+        while (errNorm > prevErrNorm && ++lambdaLg10 <= 16) {
+            step();
+            errNorm = sqrt(eval_err());
+        }
+        lambdaLg10 = max(lambdaLg10 - 1, -16);
+        double num = 0, den = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) num += (ps[k] - prev[k]) * (ps[k] - prev[k]), den += prev[k] * prev[k];
+        if (++iters >= 20 || sqrt(num) / sqrt(den) < kFltEps) return true;
+        if (iters >= stop_at) return false;
+        prevErrNorm = errNorm;
+        eval_jac();
+    }
+}
+
 // ---- cvFindExtrinsicCameraParams2 for every view ---------------------------------------------
 template <bool RAT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_init_pose(InitArgs a, CamParams cp, double* __restrict__ pose, int* __restrict__ status) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_init_pose(InitArgs a, CamParams cp, double* __restrict__ pose, int* __restrict__ status, Parked parked) {
     using M = Model<0u, false, RAT>;
     const int lane = threadIdx.x;
     const int v0 = blockIdx.x * a.VPB;
@@ -501,8 +590,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int row = live ? lane : 0;  // idle lanes shadow view 0 of the workgroup and store nothing
     const int v = v0 + row;
     const int n = a.off[v + 1] - a.off[v];
-    stage_img(a, st, v0, nv);
-    stage_obj(a, st, v0, nv);
+    auto view_of = [&](int j) { return v0 + j; };
+    stage_img(a, st, view_of, nv);
+    stage_obj(a, st, view_of, nv);
     __syncthreads();
     const float* ob = a.shared_board ? st.obj : st.obj + row * 3 * st.PS;
     auto obj = [&](int p) { return make_float3(ob[3 * p], ob[3 * p + 1], ob[3 * p + 2]); };
@@ -565,84 +655,62 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     rodrigues_m2v_polar(Rm, ps);
     // the raw image points come back for the refinement
     __syncthreads();
-    stage_img(a, st, v0, nv);
+    stage_img(a, st, view_of, nv);
     __syncthreads();
 
-    // CvLevMarq(6 parameters) with criteria (COUNT + EPS, 20, FLT_EPSILON) on the reprojection error
-    double JtJ[21], Jte[6], prev[6];
-    auto eval_err = [&]() {
-        double R[9], e2 = 0;
-        rodrigues<false>(ps, R, nullptr);
-        for (int p = 0; p < n; p++) {
-            float3 o = obj(p);
-            float2 m = irow[p];
-            double X = o.x, Y = o.y, Z = o.z;
-            double Xc = R[0] * X + R[1] * Y + R[2] * Z + ps[3];
-            double Yc = R[3] * X + R[4] * Y + R[5] * Z + ps[4];
-            double Zc = R[6] * X + R[7] * Y + R[8] * Z + ps[5];
-            PointOut<M> o2;
-            point_eval<M, false, false>(Xc, Yc, Zc, (double)m.x, (double)m.y, cp, o2);
-            e2 += o2.ex * o2.ex + o2.ey * o2.ey;
-        }
-        return e2;
-    };
-    auto eval_jac = [&]() {
-        const PoseConst q = pose_const(ps);
-        double e2 = 0;
-#pragma unroll
-        for (int k = 0; k < 21; k++) JtJ[k] = 0;
-#pragma unroll
-        for (int k = 0; k < 6; k++) Jte[k] = 0;
-        for (int p = 0; p < n; p++) {
-            float3 o = obj(p);
-            float2 m = irow[p];
-            PointOut<M> o2;
-            double jex[6], jey[6];
-            point_jacobian<M>(q, cp, (double)o.x, (double)o.y, (double)o.z, (double)m.x, (double)m.y, o2, jex, jey);
-#pragma unroll
-            for (int i = 0; i < 6; i++) {
-#pragma unroll
-                for (int j = i; j < 6; j++) JtJ[tri6(i, j)] += jex[i] * jex[j] + jey[i] * jey[j];
-                Jte[i] += jex[i] * o2.ex + jey[i] * o2.ey;
-            }
-            e2 += o2.ex * o2.ex + o2.ey * o2.ey;
-        }
-        return e2;
-    };
     int lambdaLg10 = -3, iters = 0;
-    auto step = [&]() {
-        double lambda = exp(lambdaLg10 * 2.302585092994046);
-        double L[21], invd[6], x[6];
+    double errNorm = 0;
+    const bool done = refine_pose<M>(n, obj, irow, cp, ps, lambdaLg10, iters, errNorm, true, a.cut) || !planar;
+    if (live) {
+        if (done) {
 #pragma unroll
-        for (int k = 0; k < 6; k++) x[k] = Jte[k];
-        bool pd = chol6(JtJ, lambda, L, invd);
-        chol6_fwd(L, invd, x);
-        chol6_bwd(L, invd, x);
+            for (int k = 0; k < 6; k++) pose[6 * (size_t)v + k] = planar ? ps[k] : 0.;
+            status[v] = planar ? 0 : 1;
+        } else {  // parked: a later wavefront of slow views takes it from here
+            int slot = atomicAdd(parked.count, 1);
+            parked.view[slot] = v;
+            double* d = parked.state + kParkedDoubles * (size_t)slot;
 #pragma unroll
-        for (int k = 0; k < 6; k++) ps[k] = prev[k] - (pd ? x[k] : 0.);
-    };
-    double prevErrNorm = sqrt(eval_jac()), errNorm = 0;
-    for (;;) {
-#pragma unroll
-        for (int k = 0; k < 6; k++) prev[k] = ps[k];
-        step();
-        errNorm = sqrt(eval_err());
-        while (errNorm > prevErrNorm && ++lambdaLg10 <= 16) {
-            step();
-            errNorm = sqrt(eval_err());
+            for (int k = 0; k < 6; k++) d[k] = ps[k];
+            d[6] = errNorm, d[7] = lambdaLg10, d[8] = iters;
         }
-        lambdaLg10 = max(lambdaLg10 - 1, -16);
-        double num = 0, den = 0;
-#pragma unroll
-        for (int k = 0; k < 6; k++) num += (ps[k] - prev[k]) * (ps[k] - prev[k]), den += prev[k] * prev[k];
-        if (++iters >= 20 || sqrt(num) / sqrt(den) < kFltEps) break;
-        prevErrNorm = errNorm;
-        eval_jac();
     }
+}
+
+// The views k_init_pose parked, 64 to a wavefront: their points are gathered into the stage and the
+// refinement runs on to its end.  The grid covers the worst case; workgroups past the parked count leave.
+template <bool RAT>
+__global__ __launch_bounds__(64) void k_init_pose_resume(InitArgs a, CamParams cp, double* __restrict__ pose,
+                                                         int* __restrict__ status, Parked parked) {
+    using M = Model<0u, false, RAT>;
+    const int lane = threadIdx.x;
+    const int total = *parked.count;
+    const int j0 = blockIdx.x * a.VPB;
+    if (j0 >= total) return;
+    const int nv = min(a.VPB, total - j0);
+    const Stage st = stage_layout(a, true);
+    const bool live = lane < nv;
+    const int row = live ? lane : 0;
+    auto view_of = [&](int j) { return parked.view[j0 + j]; };
+    const int v = view_of(row);
+    const int n = a.off[v + 1] - a.off[v];
+    stage_img(a, st, view_of, nv);
+    stage_obj(a, st, view_of, nv);
+    __syncthreads();
+    const float* ob = a.shared_board ? st.obj : st.obj + row * 3 * st.PS;
+    auto obj = [&](int p) { return make_float3(ob[3 * p], ob[3 * p + 1], ob[3 * p + 2]); };
+    const float2* irow = st.img + row * st.PS;
+    const double* d = parked.state + kParkedDoubles * (size_t)(j0 + row);
+    double ps[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) ps[k] = d[k];
+    double errNorm = d[6];
+    int lambdaLg10 = (int)d[7], iters = (int)d[8];
+    refine_pose<M>(n, obj, irow, cp, ps, lambdaLg10, iters, errNorm, false, 1 << 30);
     if (live) {
 #pragma unroll
-        for (int k = 0; k < 6; k++) pose[6 * (size_t)v + k] = planar ? ps[k] : 0.;
-        status[v] = planar ? 0 : 1;
+        for (int k = 0; k < 6; k++) pose[6 * (size_t)v + k] = ps[k];
+        status[v] = 0;
     }
 }
 
@@ -657,8 +725,9 @@ __global__ __launch_bounds__(64) void k_init_intrinsics(InitArgs a, double cx, d
     const int row = live ? lane : 0;
     const int v = v0 + row;
     const int n = a.off[v + 1] - a.off[v];
-    stage_img(a, st, v0, nv);
-    stage_obj(a, st, v0, nv);
+    auto view_of = [&](int j) { return v0 + j; };
+    stage_img(a, st, view_of, nv);
+    stage_obj(a, st, view_of, nv);
     __syncthreads();
     const float* ob = a.shared_board ? st.obj : st.obj + row * 3 * st.PS;
     const float2* irow = st.img + row * st.PS;
@@ -730,6 +799,8 @@ static size_t init_lds_floats(bool shared, int board_np, int PS, int VPB, bool w
 bool init_geometry(InitArgs& a, bool with_src) {
     const size_t cap = 64 * 1024;
     a.PS = a.maxnp | 1;
+    a.cut = 6;
+    if (const char* e = std::getenv("CCALIB_INIT_CUT")) a.cut = std::max(1, std::atoi(e));
     for (int vpb = 64; vpb >= 1; vpb--) {
         size_t bytes = sizeof(float) * init_lds_floats(a.shared_board != 0, a.board_np, a.PS, vpb, with_src);
         if (bytes <= cap) {
@@ -741,12 +812,17 @@ bool init_geometry(InitArgs& a, bool with_src) {
     return false;
 }
 
-void launch_init_pose(const InitArgs& a, const CamParams& cp, bool rational, double* pose, int* status, hipStream_t st) {
+void launch_init_pose(const InitArgs& a, const CamParams& cp, bool rational, double* pose, int* status, const Parked& parked,
+                      hipStream_t st) {
     int grid = (a.nviews + a.VPB - 1) / a.VPB;
-    if (rational)
-        k_init_pose<true><<<dim3(grid), dim3(64), a.lds_bytes, st>>>(a, cp, pose, status);
-    else
-        k_init_pose<false><<<dim3(grid), dim3(64), a.lds_bytes, st>>>(a, cp, pose, status);
+    (void)hipMemsetAsync(parked.count, 0, sizeof(int), st);
+    if (rational) {
+        k_init_pose<true><<<dim3(grid), dim3(64), a.lds_bytes, st>>>(a, cp, pose, status, parked);
+        k_init_pose_resume<true><<<dim3(grid), dim3(64), a.lds_bytes, st>>>(a, cp, pose, status, parked);
+    } else {
+        k_init_pose<false><<<dim3(grid), dim3(64), a.lds_bytes, st>>>(a, cp, pose, status, parked);
+        k_init_pose_resume<false><<<dim3(grid), dim3(64), a.lds_bytes, st>>>(a, cp, pose, status, parked);
+    }
 }
 
 int launch_init_intrinsics(const InitArgs& a, double cx, double cy, double* part, hipStream_t st) {

@@ -17,6 +17,15 @@ struct InitArgs {
     int PS;              // LDS row length in points (odd), set by init_geometry
     int VPB;             // views per workgroup (one lane each, <= 64), set by init_geometry
     unsigned lds_bytes;  // dynamic LDS per workgroup, set by init_geometry
+    int cut;             // pose refinement: iterations after which a view still running is parked, set by init_geometry
+};
+
+// Views whose refinement was cut short by the first pose kernel, finished by the second one.
+constexpr int kParkedDoubles = 9;  // pose (6), residual norm, damping exponent, iteration count
+struct Parked {
+    int* count;     // number of parked views (device)
+    int* view;      // nviews entries
+    double* state;  // nviews x kParkedDoubles
 };
 
 // Chooses PS, VPB and lds_bytes for the problem in `a`; with_src reserves room for the homography's
@@ -25,7 +34,8 @@ bool init_geometry(InitArgs& a, bool with_src);
 
 // cvFindExtrinsicCameraParams2 for every view: pose receives nviews x 6 (r|t), status 0 = ok,
 // 1 = the view's object points are not planar (pose left at zero).
-void launch_init_pose(const InitArgs& a, const CamParams& cp, bool rational, double* pose, int* status, hipStream_t);
+void launch_init_pose(const InitArgs& a, const CamParams& cp, bool rational, double* pose, int* status, const Parked& parked,
+                      hipStream_t);
 
 // cvInitIntrinsicParams2D: per-workgroup sums of the 2-unknown normal equations (5 doubles each);
 // returns the number of workgroups.

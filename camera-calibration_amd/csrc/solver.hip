@@ -68,6 +68,8 @@ struct ccalib_solver {
     double* d_pc = nullptr;  // nviews x kPoseConstStride: poses in the form the fused Jacobian kernel reads
     // initialisation (ccalib_solver_init_*): per-view status words, per-camera "poses are on the device" marks
     int* d_status = nullptr;
+    int* d_parked_view = nullptr;      // views the first pose kernel parked (count in entry nviews)
+    double* d_parked_state = nullptr;
     double* d_pose_init1 = nullptr;  // stereo: camera-1 planar poses until the relative pose has been taken
     bool poses_ready[2] = {false, false};
     bool pc_fresh = false;   // d_pc matches d_pose_cur
@@ -643,7 +645,7 @@ void ccalib_solver_destroy(ccalib_solver* s) {
     (void)hipFree(s->d_pose_prev), (void)hipFree(s->d_pose_cur), (void)hipFree(s->d_pose3);
     for (int b = 0; b < 2; b++) (void)hipFree(s->d_cmp[b]), (void)hipFree(s->d_blk[0][b]), (void)hipFree(s->d_blk[1][b]);
     (void)hipFree(s->d_pc), (void)hipFree(s->d_part), (void)hipFree(s->d_red);
-    (void)hipFree(s->d_status), (void)hipFree(s->d_pose_init1);
+    (void)hipFree(s->d_status), (void)hipFree(s->d_pose_init1), (void)hipFree(s->d_parked_view), (void)hipFree(s->d_parked_state);
     if (s->h_red) (void)hipHostFree(s->h_red);
     if (s->h_flag) (void)hipHostFree(s->h_flag);
     (void)hipFree(s->d_counter);
@@ -800,7 +802,12 @@ int ccalib_solver_init_poses(ccalib_solver* s, int cam, const double* K, const d
         if (!s->d_pose_init1) HIP_TRY(hipMalloc(&s->d_pose_init1, sizeof(double) * 6 * s->nviews));
         dst = s->d_pose_init1;
     }
-    launch_init_pose(a, cp, rational, dst, s->d_status, s->stream);
+    if (!s->d_parked_view) {
+        HIP_TRY(hipMalloc(&s->d_parked_view, sizeof(int) * ((size_t)s->nviews + 1)));
+        HIP_TRY(hipMalloc(&s->d_parked_state, sizeof(double) * kParkedDoubles * (size_t)s->nviews));
+    }
+    Parked parked{s->d_parked_view + s->nviews, s->d_parked_view, s->d_parked_state};
+    launch_init_pose(a, cp, rational, dst, s->d_status, parked, s->stream);
     HIP_TRY(hipGetLastError());
     std::vector<int> status(s->nviews);
     HIP_TRY(hipMemcpyAsync(status.data(), s->d_status, sizeof(int) * s->nviews, hipMemcpyDeviceToHost, s->stream));

@@ -1,2 +1,4 @@
 set -e
-timeout -k 10 500 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread 2>&1 | tail -3
+export TMPDIR=/tmp
+rm -rf gpurun_out/prof_whole
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_whole -o whole -- python3 tools/wholecall_bench.py 100000 > gpurun_out/whole_prof.log 2>&1
