@@ -171,6 +171,23 @@ def main():
                     "(v_mfma_f64_16x16x4), whose dense peak equals the FP64 vector peak on this part; achieved counts "
                     "the zero-exploiting algorithmic flops (oracle/flopcount.py), executed_* what the kernel issues",
         }
+        # the same pass on the vector ALU alone (two kernels, zero-exploiting accumulation), for comparison
+        valu = None
+        try:
+            os.environ["CCALIB_NO_FUSED"] = "1"
+            s2 = pkg.Solver(obj, ms.img, device=local_rank)
+            s2.set_start(out["intr"], mask, out["rt"])
+            k2 = s2.time_kernels(reps=20)
+            s2.close()
+            t2 = (k2["jac_shared"] + k2["jac_view"]) * 1e-3
+            valu = {"k_jac_shared_ms": round(k2["jac_shared"], 4), "k_jac_view_ms": round(k2["jac_view"], 4),
+                    "algorithmic_tflops": round((FLOPS_JAC_VIEW + 190) * points_local / t2 / 1e12, 2),
+                    "note": "the Jacobian pass without the matrix pipe (CCALIB_NO_FUSED=1): FP64 vector ALU only"}
+        except Exception as e:  # noqa: BLE001
+            valu = {"error": str(e)}
+        finally:
+            os.environ.pop("CCALIB_NO_FUSED", None)
+        roofline["valu_only_path"] = valu
         cpu = None
         whole = None
         if not args.no_cpu and world == 1:   # the CPU leg and the whole-call leg are timed at N = 1 only

@@ -1,4 +1,2 @@
 set -e
-export TMPDIR=/tmp
-rm -rf gpurun_out/prof_whole
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_whole -o whole -- python3 tools/wholecall_bench.py 100000 > gpurun_out/whole_prof.log 2>&1
+timeout -k 10 300 python bench.py --no-cpu | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['launch_ms'], d['roofline']['valu_only_path'])"
