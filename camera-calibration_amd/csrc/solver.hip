@@ -500,7 +500,7 @@ int be_step_err(void* user, double lambda, double lambda_next, const int* fidx, 
 int be_commit(void* user) {
     ccalib_solver* s = (ccalib_solver*)user;
     std::swap(s->d_pose_prev, s->d_pose_cur);  // the next step rewrites every trial pose
-    s->have_cached = s->have_cached;           // the cached sums belong to the committed Jacobian: keep
+    // (the cached Schur sums belong to the committed Jacobian and stay valid)
     return CCALIB_OK;
 }
 
