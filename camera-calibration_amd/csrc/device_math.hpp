@@ -156,6 +156,17 @@ __device__ __forceinline__ PoseConst pose_const(const double ps[6]) {
     return q;
 }
 
+// 1 / d to within an ulp: the hardware estimate and two Newton steps.  The correctly rounded quotient the
+// compiler emits for 1. / d is a chain of eleven dependent instructions (scale, estimate, four refinements,
+// fix-up) in the middle of every point's arithmetic; d here is a depth of some hundred millimetres, far from
+// the ranges that chain exists for.
+__device__ __forceinline__ double fast_rcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.), r, r);
+    r = fma(fma(-d, r, 1.), r, r);
+    return r;
+}
+
 // Everything a pass needs from one point.
 template <class M>
 struct PointOut {
@@ -172,7 +183,7 @@ __device__ __forceinline__ void point_eval(double Xc, double Yc, double Zc, doub
                                            const CamParams& cp, PointOut<M>& o) {
     const double fy = cp.fy;
     const double fx = M::aspect ? fy * cp.aspect : cp.fx;
-    double z = Zc != 0. ? 1. / Zc : 1.;
+    double z = Zc != 0. ? fast_rcp(Zc) : 1.;
     double x = Xc * z, y = Yc * z;
     double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
     double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;

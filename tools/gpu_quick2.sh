@@ -1,2 +1,4 @@
 set -e
-timeout -k 10 300 python bench.py --no-cpu | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['launch_ms'], d['roofline']['valu_only_path'])"
+timeout -k 10 120 python tools/kernel_bench.py 100000 200
+timeout -k 10 200 python bench.py --no-cpu | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['rms_px'])"
+timeout -k 10 500 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread 2>&1 | tail -3
