@@ -156,6 +156,13 @@ __device__ __forceinline__ PoseConst pose_const(const double ps[6]) {
     return q;
 }
 
+// A pose written in that form, padded to 16 doubles: the record the fused Jacobian kernel reads.
+__device__ __forceinline__ void store_pose_const(const double ps[6], double* o) {
+    PoseConst q = pose_const(ps);
+    o[0] = q.ax[0], o[1] = q.ax[1], o[2] = q.ax[2], o[3] = q.c, o[4] = q.c1, o[5] = q.s, o[6] = q.b1, o[7] = q.b2;
+    o[8] = q.b3, o[9] = q.b4, o[10] = q.t[0], o[11] = q.t[1], o[12] = q.t[2], o[13] = 0, o[14] = 0, o[15] = 0;
+}
+
 // 1 / d to within an ulp: the hardware estimate and two Newton steps.  The correctly rounded quotient the
 // compiler emits for 1. / d is a chain of eleven dependent instructions (scale, estimate, four refinements,
 // fix-up) in the middle of every point's arithmetic; d here is a depth of some hundred millimetres, far from

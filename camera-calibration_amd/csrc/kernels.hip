@@ -370,12 +370,6 @@ __global__ __launch_bounds__(kBlock, CCALIB_VIEW_MINWAVES) void k_jac_view(PassA
 // RS mod 32 in {2, 14, 18, 30} so that the 16-byte reads of 16 columns fall in disjoint banks.
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void store_pose_const(const double ps[6], double* o) {
-    PoseConst q = pose_const(ps);
-    o[0] = q.ax[0], o[1] = q.ax[1], o[2] = q.ax[2], o[3] = q.c, o[4] = q.c1, o[5] = q.s, o[6] = q.b1, o[7] = q.b2;
-    o[8] = q.b3, o[9] = q.b4, o[10] = q.t[0], o[11] = q.t[1], o[12] = q.t[2], o[13] = 0, o[14] = 0, o[15] = 0;
-}
-
 __global__ __launch_bounds__(64) void k_pose_const(const double* pose, int nviews, double* pc) {
     int v = blockIdx.x * 64 + threadIdx.x;
     if (v >= nviews) return;

@@ -66,6 +66,7 @@ struct ccalib_solver {
     double* d_cmp[2] = {nullptr, nullptr};                  // stereo: per-view composition Jacobians (SoA), per buffer
     double* d_blk[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [camera][buffer]
     double* d_pc = nullptr;  // nviews x kPoseConstStride: poses in the form the fused Jacobian kernel reads
+    double* d_pc3 = nullptr; // stereo: the same for the composed camera-1 poses (written by the composition kernel)
     // initialisation (ccalib_solver_init_*): per-view status words, per-camera "poses are on the device" marks
     int* d_status = nullptr;
     int* d_parked_view = nullptr;      // views the first pose kernel parked (count in entry nviews)
@@ -73,6 +74,7 @@ struct ccalib_solver {
     double* d_pose_init1 = nullptr;  // stereo: camera-1 planar poses until the relative pose has been taken
     bool poses_ready[2] = {false, false};
     bool pc_fresh = false;   // d_pc matches d_pose_cur
+    bool pc3_fresh = false;  // d_pc3 matches d_pose3
     // Partial results of the kernels of one pass: a bump-allocated arena, reduced by ONE column-sum
     // launch per pass whose output goes straight to pinned host memory; the host polls a flag there.
     double* d_part = nullptr;
@@ -257,7 +259,10 @@ int stereo_compose(ccalib_solver* s, bool with_jac, int buf) {
     if (s->ncams != 2) return CCALIB_OK;
     StereoLR lr;
     for (int i = 0; i < 6; i++) lr.v[i] = s->lr[i];
-    launch_compose(s->d_pose_cur, lr, s->nviews, s->npad, s->d_pose3, with_jac ? s->d_cmp[buf] : nullptr, s->stream);
+    const bool want_pc3 = with_jac && s->ops[1]->jac_fused && s->use_fused;
+    launch_compose(s->d_pose_cur, lr, s->nviews, s->npad, s->d_pose3, with_jac ? s->d_cmp[buf] : nullptr,
+                   want_pc3 ? s->d_pc3 : nullptr, s->stream);
+    s->pc3_fresh = want_pc3;
     return CCALIB_OK;
 }
 
@@ -295,9 +300,11 @@ int enqueue_jac(ccalib_solver* s, int buf, double lambda_hint, int ofs, JacLayou
         if (m->jac_fused && s->use_fused) {
             int rows = s->grid_fused * kTileViews;
             PART_TAKE(part, s, (size_t)rows * m->NRED_U);
-            if (!s->pc_fresh) launch_pose_const(a.pose, s->nviews, s->d_pc, s->stream);
-            s->pc_fresh = s->ncams == 1;  // one record array: with two cameras each pass rewrites it
-            m->jac_fused(a, cp, s->d_pc, s->grid_fused, s->d_blk[c][buf], part, s->stream);
+            double* pc = c == 0 ? s->d_pc : s->d_pc3;
+            bool& fresh = c == 0 ? s->pc_fresh : s->pc3_fresh;
+            if (!fresh) launch_pose_const(a.pose, s->nviews, pc, s->stream);
+            fresh = true;
+            m->jac_fused(a, cp, pc, s->grid_fused, s->d_blk[c][buf], part, s->stream);
             if ((rc = queue_colsum(s, part, rows, m->NRED_U, ofs))) return rc;
         } else {
             PART_TAKE(part, s, (size_t)s->grid_red * m->NRED_U);
@@ -454,9 +461,13 @@ int be_step_err(void* user, double lambda, double lambda_next, const int* fidx, 
         int kc = s->kcols();
         for (int k = 0; k < kStereoMaxCols; k++)
             sd.v[k] = k < kc && s->kcol_to_shared(k) < s->ns() ? dfull[s->kcol_to_shared(k)] : 0.;
+        const bool want_pc = s->ops[0]->jac_fused && s->use_fused;
         if (!launch_stereo_backsub(s->ops[0]->NC, s->d_blk[0][cur], s->d_blk[1][cur], s->d_cmp[cur], s->lr_jac[cur],
-                                   s->npad, s->nviews, lambda, sd, s->d_pose_prev, s->d_pose_cur, npart, s->stream))
+                                   s->npad, s->nviews, lambda, sd, s->d_pose_prev, s->d_pose_cur, npart,
+                                   want_pc ? s->d_pc : nullptr, s->stream))
             return set_error(CCALIB_ERR_UNSUPPORTED, "stereo column count %d is not built in", s->ops[0]->NC);
+        s->pc_fresh = want_pc;
+        s->pc3_fresh = false;  // camera 1's poses follow in the composition kernel
     }
     if ((rc = queue_colsum(s, npart, s->nblk64, 2, 0))) return rc;
     store_shared(s, shared_new);
@@ -623,6 +634,7 @@ int ccalib_solver_create(ccalib_solver** out, int device, int ncams, int nviews,
     HIP_TRY(hipMalloc(&s->d_pc, sizeof(double) * kPoseConstStride * nviews));
     if (ncams == 2) {
         HIP_TRY(hipMalloc(&s->d_pose3, sizeof(double) * 6 * nviews));
+        HIP_TRY(hipMalloc(&s->d_pc3, sizeof(double) * kPoseConstStride * nviews));
         for (int b = 0; b < 2; b++) HIP_TRY(hipMalloc(&s->d_cmp[b], sizeof(double) * kCmpRows * s->npad));
     }
     HIP_TRY(hipMalloc(&s->d_red, sizeof(double) * ccalib_solver::kRedCap));
@@ -644,7 +656,7 @@ void ccalib_solver_destroy(ccalib_solver* s) {
     (void)hipFree(s->d_obj), (void)hipFree(s->d_off), (void)hipFree(s->d_img[0]), (void)hipFree(s->d_img[1]);
     (void)hipFree(s->d_pose_prev), (void)hipFree(s->d_pose_cur), (void)hipFree(s->d_pose3);
     for (int b = 0; b < 2; b++) (void)hipFree(s->d_cmp[b]), (void)hipFree(s->d_blk[0][b]), (void)hipFree(s->d_blk[1][b]);
-    (void)hipFree(s->d_pc), (void)hipFree(s->d_part), (void)hipFree(s->d_red);
+    (void)hipFree(s->d_pc), (void)hipFree(s->d_pc3), (void)hipFree(s->d_part), (void)hipFree(s->d_red);
     (void)hipFree(s->d_status), (void)hipFree(s->d_pose_init1), (void)hipFree(s->d_parked_view), (void)hipFree(s->d_parked_state);
     if (s->h_red) (void)hipHostFree(s->h_red);
     if (s->h_flag) (void)hipHostFree(s->h_flag);
@@ -707,7 +719,7 @@ int ccalib_solver_set_start(ccalib_solver* s, const double* intr, const unsigned
     if (rt) HIP_TRY(hipMemcpy(s->d_pose_cur, rt, sizeof(double) * 6 * s->nviews, hipMemcpyHostToDevice));
     s->poses_ready[0] = s->poses_ready[1] = false;  // the LM loop takes the pose buffers over
     s->started = true;
-    s->pc_fresh = false;
+    s->pc_fresh = s->pc3_fresh = false;
     s->have_cached = false;
     s->spec_valid = false;
     s->steps_since_jac = 0;

@@ -79,7 +79,7 @@ __device__ __forceinline__ void mul33(const double A[9], const double B[9], doub
 }
 
 __global__ __launch_bounds__(64) void k_compose(const double* pose1, StereoLR lr, int nviews, int npad, double* pose3,
-                                                double* cmp) {
+                                                double* cmp, double* pc3) {
     int v = blockIdx.x * 64 + threadIdx.x;
     if (v >= nviews) return;
     const double* p = pose1 + 6 * (size_t)v;
@@ -100,6 +100,10 @@ __global__ __launch_bounds__(64) void k_compose(const double* pose1, StereoLR lr
     q[0] = m.r[0], q[1] = m.r[1], q[2] = m.r[2];
 #pragma unroll
     for (int i = 0; i < 3; i++) q[3 + i] = R2[i * 3] * t1[0] + R2[i * 3 + 1] * t1[1] + R2[i * 3 + 2] * t1[2] + lr.v[3 + i];
+    if (pc3) {  // camera 1's pose in the form the fused Jacobian kernel reads
+        double p3[6] = {q[0], q[1], q[2], q[3], q[4], q[5]};
+        store_pose_const(p3, pc3 + 16 * (size_t)v);
+    }
     if (!jac) return;
 #pragma unroll
     for (int j = 0; j < 3; j++) {
@@ -318,7 +322,7 @@ __global__ __launch_bounds__(64) void k_stereo_schur(const double* blk0, const d
 template <int NC0, int NC1>
 __global__ __launch_bounds__(64) void k_stereo_backsub(const double* blk0, const double* blk1, const double* cmp,
                                                        StereoLR lr, int npad, int nviews, double lambda, StereoDelta d,
-                                                       const double* pose_prev, double* pose_cur, double* part) {
+                                                       const double* pose_prev, double* pose_cur, double* part, double* pc) {
     int v = blockIdx.x * 64 + threadIdx.x;
     bool live = v < nviews;
     int vv = live ? v : nviews - 1;
@@ -355,15 +359,17 @@ __global__ __launch_bounds__(64) void k_stereo_backsub(const double* blk0, const
     bool ok = chol6(s.Vu, lambda, L, invd);
     chol6_fwd(L, invd, rhs);
     chol6_bwd(L, invd, rhs);
-    double dn = 0, pn = 0;
+    double dn = 0, pn = 0, pnew[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) {
         double pv = pose_prev[6 * (size_t)vv + k];
         double dd = ok ? rhs[k] : 0.;
-        if (live) pose_cur[6 * (size_t)vv + k] = pv - dd;
+        pnew[k] = pv - dd;
+        if (live) pose_cur[6 * (size_t)vv + k] = pnew[k];
         dn += dd * dd;
         pn += pv * pv;
     }
+    if (pc && live) store_pose_const(pnew, pc + 16 * (size_t)vv);
     dn = wave_sum(live ? dn : 0.);
     pn = wave_sum(live ? pn : 0.);
     if (threadIdx.x == 0) {
@@ -374,9 +380,9 @@ __global__ __launch_bounds__(64) void k_stereo_backsub(const double* blk0, const
 
 }  // namespace
 
-void launch_compose(const double* pose1, const StereoLR& lr, int nviews, int npad, double* pose3, double* cmp,
+void launch_compose(const double* pose1, const StereoLR& lr, int nviews, int npad, double* pose3, double* cmp, double* pc3,
                     hipStream_t st) {
-    hipLaunchKernelGGL(k_compose, dim3((nviews + 63) / 64), dim3(64), 0, st, pose1, lr, nviews, npad, pose3, cmp);
+    hipLaunchKernelGGL(k_compose, dim3((nviews + 63) / 64), dim3(64), 0, st, pose1, lr, nviews, npad, pose3, cmp, pc3);
 }
 
 template <int NC>
@@ -392,9 +398,9 @@ static void schur_t(dim3 grid, hipStream_t st, const double* blk0, const double*
 template <int NC>
 static void backsub_t(dim3 grid, hipStream_t st, const double* blk0, const double* blk1, const double* cmp,
                       const StereoLR& lr, int npad, int nviews, double lambda, const StereoDelta& d,
-                      const double* pose_prev, double* pose_cur, double* part) {
+                      const double* pose_prev, double* pose_cur, double* part, double* pc) {
     hipLaunchKernelGGL((k_stereo_backsub<NC, NC>), grid, dim3(64), 0, st, blk0, blk1, cmp, lr, npad, nviews, lambda, d,
-                       pose_prev, pose_cur, part);
+                       pose_prev, pose_cur, part, pc);
 }
 
 // column counts of the built-in column sets (kernels.hip)
@@ -424,9 +430,9 @@ bool launch_stereo_schur(int nc, const double* blk0, const double* blk1, const d
 
 bool launch_stereo_backsub(int nc, const double* blk0, const double* blk1, const double* cmp, const StereoLR& lr,
                            int npad, int nviews, double lambda, const StereoDelta& d, const double* pose_prev,
-                           double* pose_cur, double* part, hipStream_t st) {
+                           double* pose_cur, double* part, double* pc, hipStream_t st) {
     dim3 grid((nviews + 63) / 64);
-    CCALIB_FOR_NC(nc, backsub_t, grid, st, blk0, blk1, cmp, lr, npad, nviews, lambda, d, pose_prev, pose_cur, part);
+    CCALIB_FOR_NC(nc, backsub_t, grid, st, blk0, blk1, cmp, lr, npad, nviews, lambda, d, pose_prev, pose_cur, part, pc);
     return true;
 }
 

@@ -14,8 +14,9 @@ struct StereoDelta {
     double v[kStereoMaxCols];  // step of [om_LR T_LR | camera-0 columns | camera-1 columns]
 };
 
-// pose3 = (om_LR,T_LR) o pose1 for every view; cmp (may be null) receives the derivatives.
-void launch_compose(const double* pose1, const StereoLR& lr, int nviews, int npad, double* pose3, double* cmp,
+// pose3 = (om_LR,T_LR) o pose1 for every view; cmp (may be null) receives the derivatives, pc3 (may be null)
+// pose3 as the 16-double records the fused Jacobian kernel reads.
+void launch_compose(const double* pose1, const StereoLR& lr, int nviews, int npad, double* pose3, double* cmp, double* pc3,
                     hipStream_t st);
 // The three per-view kernels below need the relative pose the Jacobian pass was taken at (`lr`).
 // Both cameras use the same column set (nc columns each).  They return false for a column count
@@ -30,6 +31,6 @@ bool launch_stereo_schur(int nc, const double* blk0, const double* blk1, const d
                          int nviews, double lambda, double* part, hipStream_t st);
 bool launch_stereo_backsub(int nc, const double* blk0, const double* blk1, const double* cmp, const StereoLR& lr,
                            int npad, int nviews, double lambda, const StereoDelta& d, const double* pose_prev,
-                           double* pose_cur, double* part, hipStream_t st);
+                           double* pose_cur, double* part, double* pc, hipStream_t st);  // pc: trial poses as records, or null
 
 }  // namespace ccalib
