@@ -400,6 +400,8 @@ def test_two_ranks_shard_views_callback_allreduce():
     out = _run_shard_worker("callback", 29621)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "GPU_SHARDED_OK callback" in out.stdout
+    assert "GPU_SHARDED_INIT_OK callback" in out.stdout           # device initialisation summed over ranks
+    assert "GPU_SHARDED_STEREO_OK callback" in out.stdout         # stereoCalibrate sharded over pairs
 
 
 def test_rccl_allreduce_path(pkg, synth):
