@@ -65,9 +65,9 @@ static void lm_step(orc_levmarq* lm) {
     int* idx = (int*)malloc(sizeof(int) * n);
     for (int i = 0; i < n; i++)
         if (lm->mask[i]) idx[nz++] = i;
-    double* A = (double*)malloc(sizeof(double) * (size_t)nz * nz);
-    double* b = (double*)malloc(sizeof(double) * nz);
-    double* x = (double*)malloc(sizeof(double) * nz);
+    double* A = (double*)calloc((size_t)nz * nz + 1, sizeof(double));
+    double* b = (double*)calloc((size_t)nz + 1, sizeof(double));
+    double* x = (double*)calloc((size_t)nz + 1, sizeof(double));
     for (int i = 0; i < nz; i++) {
         b[i] = lm->JtErr[idx[i]];
         for (int j = 0; j < nz; j++) A[(size_t)i * nz + j] = lm->JtJ[(size_t)idx[i] * n + idx[j]];
