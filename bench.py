@@ -67,8 +67,16 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # CCALIB_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks
+        # (ranks then share GPUs and every sum goes through a host callback)
+        backend = os.environ.get("CCALIB_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = local_rank % max(1, torch.cuda.device_count())
+            dist.init_process_group(backend=backend)
+            args.allreduce = "torch"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the library has no CPU path)")
     torch.cuda.set_device(local_rank)
@@ -103,7 +111,7 @@ def main():
                 print(f"[rank {rank}] in-stream RCCL unavailable ({e}); using torch.distributed", file=sys.stderr)
                 mode = "torch"
         if mode == "torch":
-            gloo = dist.new_group(backend="gloo")
+            gloo = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else None
 
             def allreduce(buf):
                 t = torch.from_numpy(buf)
@@ -127,7 +135,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     out = solver.get()
