@@ -174,7 +174,7 @@ def main():
             "algorithmic_bytes_per_launch": int(BYTES_JAC_VIEW * points_local),
             "hbm_achieved_GBps": round(BYTES_JAC_VIEW * points_local / t_jac / 1e9, 1),
             "hbm_frac": round(BYTES_JAC_VIEW * points_local / t_jac / 1e9 / PEAK_HBM_GBPS, 4),
-            "other_kernels_ms": {"k_jac_shared": round(km["jac_shared"], 4), "k_err": round(km["err"], 4)},
+            "other_kernels_ms": {"k_jac_shared": round(km["jac_shared"], 4), "k_err_wave": round(km["err"], 4)},
             "note": "FP64 path: the normal-equation update of a view is one A^T A product on the FP64 matrix pipe "
                     "(v_mfma_f64_16x16x4), whose dense peak equals the FP64 vector peak on this part; achieved counts "
                     "the zero-exploiting algorithmic flops (oracle/flopcount.py), executed_* what the kernel issues",

@@ -13,10 +13,11 @@
 //   * the G-lane kernels: a view is owned by G consecutive lanes of one wavefront (G = 2..64, power
 //     of two); lane g handles points g, g+G, ...; image points are read in the caller's own layout
 //     (view-major float2), so the G lanes of a view read one contiguous run:
-//       k_err / k_reproj  residuals only, one accumulator per lane;
+//       k_reproj          projected points and per-view squared error;
 //       k_jac_shared      the shared (intrinsic) block JiT*Ji, JiT*e, eT*e, reduced once per workgroup;
 //       k_jac_view        the per-view blocks JeT*Je, JeT*e, JiT*Je, butterfly-reduced over the G lanes
 //     (the last two serve the rational column sets, whose columns do not fit one 16-wide tile);
+//   * k_err_wave    residual sum: one wavefront per view, one lane per point, poses as records;
 //   * k_schur / k_backsub  one lane per view: 6x6 Cholesky elimination of the view block;
 //   * k_colsum      every column sum of a pass in one launch, written where the host polls.
 // Reductions are fixed-order trees (no atomics on data), so results are bitwise reproducible.
@@ -143,23 +144,12 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[N], double* red
 }
 
 // Walks the points g, g+G, ... of one staged view; body(X, Y, Z, u, v) is called once per point.
-// `local` is the view's first point relative to the stage.  Two points are in flight per trip: a point's
-// arithmetic is one long dependent chain (a division in the middle), and with the few wavefronts per SIMD the
-// stage leaves room for, a second independent chain is what keeps the FP64 pipe issuing.
-// (PAIR; the Jacobian kernels, whose accumulators already fill the register file, take one point at a time.)
-template <int G, bool PAIR = false, class Body>
+// `local` is the view's first point relative to the stage.
+template <int G, class Body>
 __device__ __forceinline__ void for_points(const PassArgs& a, const Lane<G>& l, int local, int np, Body&& body) {
     const float* obj = a.shared_board ? l.board : l.staged ? l.sobj + 3 * local : a.obj + 3 * (size_t)(l.base + local);
     const float2* img = l.staged ? l.simg + local : a.img + (l.base + local);
-    int p = l.g;
-    for (; PAIR && p + G < np; p += 2 * G) {
-        float2 m0 = img[p], m1 = img[p + G];
-        float X0 = obj[3 * p], Y0 = obj[3 * p + 1], Z0 = obj[3 * p + 2];
-        float X1 = obj[3 * (p + G)], Y1 = obj[3 * (p + G) + 1], Z1 = obj[3 * (p + G) + 2];
-        body((double)X0, (double)Y0, (double)Z0, (double)m0.x, (double)m0.y);
-        body((double)X1, (double)Y1, (double)Z1, (double)m1.x, (double)m1.y);
-    }
-    for (; p < np; p += G) {
+    for (int p = l.g; p < np; p += G) {
         float2 m = img[p];
         float X = obj[3 * p], Y = obj[3 * p + 1], Z = obj[3 * p + 2];
         body((double)X, (double)Y, (double)Z, (double)m.x, (double)m.y);
@@ -167,26 +157,38 @@ __device__ __forceinline__ void for_points(const PassArgs& a, const Lane<G>& l, 
 }
 
 // ---- residual pass -------------------------------------------------------------------------
-template <bool RAT, int G>
-__global__ __launch_bounds__(kBlock) void k_err(PassArgs a, CamParams cp, double* part) {
+// Residual pass, one wavefront per view and one lane per point (64 points at a time), poses taken as the
+// 16-double records the fused Jacobian kernel reads.  A point's arithmetic is one dependent chain, so what
+// keeps the FP64 pipe issuing is the number of wavefronts per SIMD: with nothing staged in LDS but the shared
+// board, eight fit (the G-lane layout below, with its per-wavefront stage, allows two).
+template <bool RAT>
+__global__ __launch_bounds__(kBlock) void k_err_wave(PassArgs a, CamParams cp, const double* __restrict__ pc,
+                                                     double* part) {
     using M = Model<0u, false, RAT>;
     __shared__ double red[kWaves];
     stage_board(a);
-    Lane<G> l(a);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nwaves = gridDim.x * kWaves;
     double acc[1] = {0.};
-    for (; l.v0 < a.nviews; l.next_round()) {
-        ViewHead h = load_head(a, l.v);
-        int base = stage_views(a, l);
-        double R[9];
-        rodrigues<false>(h.ps, R, nullptr);
-        for_points<G, true>(a, l, h.first - base, h.np, [&](double X, double Y, double Z, double u, double v) {
-            double Xc = R[0] * X + R[1] * Y + R[2] * Z + h.ps[3];
-            double Yc = R[3] * X + R[4] * Y + R[5] * Z + h.ps[4];
-            double Zc = R[6] * X + R[7] * Y + R[8] * Z + h.ps[5];
-            PointOut<M> o;
-            point_eval<M, false, false>(Xc, Yc, Zc, u, v, cp, o);
-            acc[0] += o.ex * o.ex + o.ey * o.ey;
-        });
+    for (int v = __builtin_amdgcn_readfirstlane(blockIdx.x * kWaves + w); v < a.nviews; v += nwaves) {
+        const int first = a.off[v], np = a.off[v + 1] - first;
+        const double* q = pc + kPoseConstStride * (size_t)v;  // wave-uniform: scalar loads
+        const double ax = q[0], ay = q[1], az = q[2], c = q[3], c1 = q[4], sn = q[5], tx = q[10], ty = q[11], tz = q[12];
+        for (int p0 = 0; p0 < np; p0 += 64) {
+            const int p = p0 + lane;
+            if (p < np) {
+                const float2 m = a.img[first + p];
+                const float* ob = a.shared_board ? lds_dyn + 3 * p : a.obj + 3 * (size_t)(first + p);
+                const double X = ob[0], Y = ob[1], Z = ob[2];
+                const double d = c1 * (ax * X + ay * Y + az * Z);
+                const double Xc = tx + c * X + d * ax + sn * (ay * Z - az * Y);
+                const double Yc = ty + c * Y + d * ay + sn * (az * X - ax * Z);
+                const double Zc = tz + c * Z + d * az + sn * (ax * Y - ay * X);
+                PointOut<M> o;
+                point_eval<M, false, false>(Xc, Yc, Zc, (double)m.x, (double)m.y, cp, o);
+                acc[0] += o.ex * o.ex + o.ey * o.ey;
+            }
+        }
     }
     block_reduce_store<1>(acc, red, part + blockIdx.x);
 }
@@ -850,14 +852,13 @@ const ModelOps* find_model(unsigned need_mask, bool aspect, bool need_rational) 
     return best;
 }
 
-void launch_err(const PassArgs& a, const CamParams& cp, bool rational, int grid, double* part, hipStream_t st) {
-    dispatch_G(a.G, [&](auto g) {
-        constexpr int GG = decltype(g)::value;
-        if (rational)
-            k_err<true, GG><<<dim3(grid), dim3(kBlock), a.lds_bytes, st>>>(a, cp, part);
-        else
-            k_err<false, GG><<<dim3(grid), dim3(kBlock), a.lds_bytes, st>>>(a, cp, part);
-    });
+void launch_err_wave(const PassArgs& a, const CamParams& cp, bool rational, const double* pc, int grid, double* part,
+                     hipStream_t st) {
+    const unsigned lds = (unsigned)(sizeof(float) * (a.shared_board ? 3 * (size_t)a.board_np : 0));
+    if (rational)
+        k_err_wave<true><<<dim3(grid), dim3(kBlock), lds, st>>>(a, cp, pc, part);
+    else
+        k_err_wave<false><<<dim3(grid), dim3(kBlock), lds, st>>>(a, cp, pc, part);
 }
 
 void launch_reproj(const PassArgs& a, const CamParams& cp, bool rational, int grid, float2* proj, double* view_err,

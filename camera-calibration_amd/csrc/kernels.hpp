@@ -72,7 +72,9 @@ struct ModelOps {
 
 // Smallest built-in column set that covers `need_mask` (bits over the 12 modelled intrinsics).
 const ModelOps* find_model(unsigned need_mask, bool aspect, bool need_rational);
-void launch_err(const PassArgs&, const CamParams&, bool rational, int grid, double* part, hipStream_t);
+// sum of squared residuals from pose records (pc: nviews x kPoseConstStride), one wavefront per view
+void launch_err_wave(const PassArgs&, const CamParams&, bool rational, const double* pc, int grid, double* part,
+                     hipStream_t);
 // projected pixels (as float, optional) and the squared reprojection error of every view
 void launch_reproj(const PassArgs&, const CamParams&, bool rational, int grid, float2* proj, double* view_err,
                    hipStream_t);

@@ -52,6 +52,7 @@ struct ccalib_solver {
     int grid_view = 0;  // per-view kernels: every wavefront does one round
     int grid_red = 0;   // reducing kernels: fewer workgroups, several rounds each, one reduction at the end
     int grid_fused = 0; // fused Jacobian kernel: workgroups striding over tiles of kTileViews views
+    int grid_err = 0;   // residual kernel: one wavefront per view, striding
     bool use_fused = true;
     unsigned lds_bytes = 0;
     hipStream_t stream = nullptr;
@@ -223,7 +224,7 @@ size_t part_capacity(const ccalib_solver* s) {
     size_t n = 0;
     int kc = s->kcols();
     for (int c = 0; c < s->ncams; c++)
-        n += (size_t)std::max(s->grid_fused * kTileViews, s->grid_red) * s->ops[c]->NRED_U + 64 + (size_t)s->grid_red + 64;
+        n += (size_t)std::max(s->grid_fused * kTileViews, s->grid_red) * s->ops[c]->NRED_U + 64 + (size_t)std::max(s->grid_red, s->grid_err) + 64;
     n += (size_t)s->nblk64 * (kc * (kc + 1) / 2 + kc) + 64;  // Schur sums
     n += (size_t)s->nblk64 * 2 + 64;                          // step norms
     if (s->ncams == 2) n += (size_t)s->nblk64 * (27 + 6 * s->ops[1]->NC) + 64;
@@ -231,6 +232,16 @@ size_t part_capacity(const ccalib_solver* s) {
 }
 
 const double* cam_pose(const ccalib_solver* s, int cam) { return cam == 0 ? s->d_pose_cur : s->d_pose3; }
+
+// Residual pass of camera c at the current poses: partial sums (s->grid_err of them) into `part`.
+void enqueue_err(ccalib_solver* s, int c, const CamParams& cp, double* part) {
+    PassArgs a = pass_args(s, c, cam_pose(s, c));
+    double* pc = c == 0 ? s->d_pc : s->d_pc3;
+    bool& fresh = c == 0 ? s->pc_fresh : s->pc3_fresh;
+    if (!fresh) launch_pose_const(a.pose, s->nviews, pc, s->stream);
+    fresh = true;
+    launch_err_wave(a, cp, s->rational[c], pc, s->grid_err, part, s->stream);
+}
 
 void current_shared(const ccalib_solver* s, double* shared) {
     if (s->ncams == 1) {
@@ -259,7 +270,7 @@ int stereo_compose(ccalib_solver* s, bool with_jac, int buf) {
     if (s->ncams != 2) return CCALIB_OK;
     StereoLR lr;
     for (int i = 0; i < 6; i++) lr.v[i] = s->lr[i];
-    const bool want_pc3 = with_jac && s->ops[1]->jac_fused && s->use_fused;
+    const bool want_pc3 = !with_jac || (s->ops[1]->jac_fused && s->use_fused);  // the residual kernel reads records too
     launch_compose(s->d_pose_cur, lr, s->nviews, s->npad, s->d_pose3, with_jac ? s->d_cmp[buf] : nullptr,
                    want_pc3 ? s->d_pc3 : nullptr, s->stream);
     s->pc3_fresh = want_pc3;
@@ -494,10 +505,9 @@ int be_step_err(void* user, double lambda, double lambda_next, const int* fidx, 
         if ((rc = stereo_compose(s, false, cur))) return rc;
         for (int c = 0; c < s->ncams; c++) {
             CamParams cp = cam_params(s->intr[c], s->aspect[c]);
-            PassArgs a = pass_args(s, c, cam_pose(s, c));
-            PART_TAKE(epart, s, (size_t)s->grid_red);
-            launch_err(a, cp, s->rational[c], s->grid_red, epart, s->stream);
-            if ((rc = queue_colsum(s, epart, s->grid_red, 1, 2 + c))) return rc;
+            PART_TAKE(epart, s, (size_t)s->grid_err);
+            enqueue_err(s, c, cp, epart);
+            if ((rc = queue_colsum(s, epart, s->grid_err, 1, 2 + c))) return rc;
         }
         if ((rc = finish_reduction(s, 2 + s->ncams))) return rc;
         *err = s->h_red[2] + (s->ncams == 2 ? s->h_red[3] : 0.);
@@ -613,6 +623,7 @@ int ccalib_solver_create(ccalib_solver** out, int device, int ncams, int nviews,
     if (const char* e = std::getenv("CCALIB_GRID_FUSED"))
         s->grid_fused = std::max(1, std::min((nviews + kTileViews - 1) / kTileViews, std::atoi(e)));
     if (const char* e = std::getenv("CCALIB_NO_FUSED")) s->use_fused = std::atoi(e) == 0;
+    s->grid_err = std::min((nviews + 3) / 4, 2048);  // eight wavefronts per SIMD
     if (const char* e = std::getenv("CCALIB_NO_AHEAD")) s->speculate = std::atoi(e) == 0;
     if (fused_geom(s->maxnp, s->shared_board, s->board_np).lds_bytes > 64 * 1024) s->use_fused = false;
     s->nblk64 = (nviews + 63) / 64;
@@ -935,10 +946,9 @@ int ccalib_solver_eval_error(ccalib_solver* s, double* err) {
     for (int c = 0; c < s->ncams; c++) {
         CamParams cp = cam_params(s->intr[c], s->aspect[c]);
         if (s->aspect[c] != 0) cp.fx = cp.fy * s->aspect[c];
-        PassArgs a = pass_args(s, c, cam_pose(s, c));
-        PART_TAKE(epart, s, (size_t)s->grid_red);
-        launch_err(a, cp, s->rational[c], s->grid_red, epart, s->stream);
-        if ((rc = queue_colsum(s, epart, s->grid_red, 1, c))) return rc;
+        PART_TAKE(epart, s, (size_t)s->grid_err);
+        enqueue_err(s, c, cp, epart);
+        if ((rc = queue_colsum(s, epart, s->grid_err, 1, c))) return rc;
     }
     if ((rc = finish_reduction(s, s->ncams))) return rc;
     *err = s->h_red[0] + (s->ncams == 2 ? s->h_red[1] : 0.);
@@ -997,7 +1007,7 @@ int ccalib_solver_time_kernels(ccalib_solver* s, int reps, double ms[3]) {
     const ModelOps* m = s->ops[0];
     const bool fused = m->jac_fused && s->use_fused;
     s->part_used = 0;
-    PART_TAKE(tpart, s, (size_t)std::max(s->grid_red, s->grid_fused * kTileViews) * m->NRED_U);
+    PART_TAKE(tpart, s, (size_t)std::max(std::max(s->grid_red, s->grid_err), s->grid_fused * kTileViews) * m->NRED_U);
     s->part_used = 0;
     CamParams cp = cam_params(s->intr[0], s->aspect[0]);
     PassArgs a = pass_args(s, 0, s->d_pose_cur);
@@ -1015,7 +1025,7 @@ int ccalib_solver_time_kernels(ccalib_solver* s, int reps, double ms[3]) {
             else if (which == 1)
                 m->jac_view(a, cp, s->grid_view, s->d_blk[0][s->cur], s->npad, s->stream);
             else
-                launch_err(a, cp, s->rational[0], s->grid_red, tpart, s->stream);
+                enqueue_err(s, 0, cp, tpart);
         };
         launch();  // warm-up
         HIP_TRY(hipEventRecord(e0, s->stream));
