@@ -157,7 +157,7 @@ __device__ __forceinline__ PoseConst pose_const(const double ps[6]) {
 }
 
 // A pose written in that form, padded to 16 doubles: the record the fused Jacobian kernel reads.
-__device__ __forceinline__ void store_pose_const(const double ps[6], double* o) {
+__device__ __forceinline__ void store_pose_const(const double ps[6], double (&o)[16]) {
     PoseConst q = pose_const(ps);
     o[0] = q.ax[0], o[1] = q.ax[1], o[2] = q.ax[2], o[3] = q.c, o[4] = q.c1, o[5] = q.s, o[6] = q.b1, o[7] = q.b2;
     o[8] = q.b3, o[9] = q.b4, o[10] = q.t[0], o[11] = q.t[1], o[12] = q.t[2], o[13] = 0, o[14] = 0, o[15] = 0;
@@ -360,6 +360,25 @@ struct LaneReducer {
         k = 0;
     }
 };
+
+// Stores one row of NV doubles per lane to a row-major global array (row r of the wavefront at out + r * NV, rows
+// 0..nrows-1 exist) through LDS, so that the wavefront writes the rows' contiguous bytes with full-width stores
+// instead of 64 lanes each touching its own cache line NV times.  sm: 64 * (NV + 1) doubles, one wavefront.
+template <int NV>
+__device__ __forceinline__ void wave_store_rows(const double (&vals)[NV], double* sm, double* out, int nrows) {
+    const int lane = threadIdx.x & 63;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < NV; k++) sm[lane * (NV + 1) + k] = vals[k];
+    __builtin_amdgcn_wave_barrier();
+    const int total = nrows * NV;
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const int i = j * 64 + lane;
+        if (i < total) out[i] = sm[(i / NV) * (NV + 1) + i % NV];
+    }
+    __builtin_amdgcn_wave_barrier();
+}
 
 // In-place lower Cholesky of a symmetric 6x6 given by its upper triangle packed row-major
 // (21 values: (0,0) (0,1) .. (0,5) (1,1) ..).  On return L[i][j] (j <= i) and the reciprocal

@@ -378,7 +378,10 @@ __global__ __launch_bounds__(64) void k_pose_const(const double* pose, int nview
     double ps[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) ps[k] = pose[6 * (size_t)v + k];
-    store_pose_const(ps, pc + kPoseConstStride * (size_t)v);
+    double rec[16];
+    store_pose_const(ps, rec);
+#pragma unroll
+    for (int k = 0; k < 16; k++) pc[kPoseConstStride * (size_t)v + k] = rec[k];
 }
 
 template <class M, bool SHARED, bool MULTI>
@@ -694,17 +697,24 @@ __global__ __launch_bounds__(64) void k_backsub(const double* blk, int npad, int
     bool ok = chol6(Vu, lambda, L, invd);
     chol6_fwd(L, invd, rhs);
     chol6_bwd(L, invd, rhs);
+    // the wavefront's 64 poses (and pose records) are contiguous in memory: written as such
+    __shared__ double sm[64 * 17];
+    const int v0 = blockIdx.x * 64, nlive = min(64, nviews - v0);
     double dn = 0, pn = 0, pnew[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) {
         double pv = pose_prev[6 * (size_t)vv + k];
         double d = ok ? rhs[k] : 0.;  // a singular view block gets no update
         pnew[k] = pv - d;
-        if (live) pose_cur[6 * (size_t)vv + k] = pnew[k];
         dn += d * d;
         pn += pv * pv;
     }
-    if (pc && live) store_pose_const(pnew, pc + kPoseConstStride * (size_t)vv);
+    wave_store_rows<6>(pnew, sm, pose_cur + 6 * (size_t)v0, nlive);
+    if (pc) {
+        double rec[16];
+        store_pose_const(pnew, rec);
+        wave_store_rows<16>(rec, sm, pc + kPoseConstStride * (size_t)v0, nlive);
+    }
     dn = wave_sum(live ? dn : 0.);
     pn = wave_sum(live ? pn : 0.);
     if (threadIdx.x == 0) {

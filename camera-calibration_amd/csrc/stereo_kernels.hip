@@ -101,8 +101,10 @@ __global__ __launch_bounds__(64) void k_compose(const double* pose1, StereoLR lr
 #pragma unroll
     for (int i = 0; i < 3; i++) q[3 + i] = R2[i * 3] * t1[0] + R2[i * 3 + 1] * t1[1] + R2[i * 3 + 2] * t1[2] + lr.v[3 + i];
     if (pc3) {  // camera 1's pose in the form the fused Jacobian kernel reads
-        double p3[6] = {q[0], q[1], q[2], q[3], q[4], q[5]};
-        store_pose_const(p3, pc3 + 16 * (size_t)v);
+        double p3[6] = {q[0], q[1], q[2], q[3], q[4], q[5]}, rec[16];
+        store_pose_const(p3, rec);
+#pragma unroll
+        for (int k = 0; k < 16; k++) pc3[16 * (size_t)v + k] = rec[k];
     }
     if (!jac) return;
 #pragma unroll
@@ -365,11 +367,17 @@ __global__ __launch_bounds__(64) void k_stereo_backsub(const double* blk0, const
         double pv = pose_prev[6 * (size_t)vv + k];
         double dd = ok ? rhs[k] : 0.;
         pnew[k] = pv - dd;
-        if (live) pose_cur[6 * (size_t)vv + k] = pnew[k];
         dn += dd * dd;
         pn += pv * pv;
     }
-    if (pc && live) store_pose_const(pnew, pc + 16 * (size_t)vv);
+    __shared__ double sm[64 * 17];
+    const int v0 = blockIdx.x * 64, nlive = min(64, nviews - v0);
+    wave_store_rows<6>(pnew, sm, pose_cur + 6 * (size_t)v0, nlive);
+    if (pc) {
+        double rec[16];
+        store_pose_const(pnew, rec);
+        wave_store_rows<16>(rec, sm, pc + 16 * (size_t)v0, nlive);
+    }
     dn = wave_sum(live ? dn : 0.);
     pn = wave_sum(live ? pn : 0.);
     if (threadIdx.x == 0) {
