@@ -259,6 +259,41 @@ def test_stereo_fix_intrinsic_default_flag(pkg, orc, synth):
     assert np.allclose(got["T"], [-60.0, 0.5, 1.0], atol=0.5)
 
 
+@pytest.mark.parametrize("case", ["aspect8", "rational12", "ragged"])
+def test_stereo_other_column_sets_and_ragged_views(pkg, orc, synth, case):
+    """stereoCalibrate over the remaining built-in column sets (8 columns per camera with a fixed aspect ratio, all
+    twelve with the rational model: the two-kernel vector path) and over views that each see their own subset of
+    the board (per-view object points, different point counts)."""
+    obj = synth.chessboard(9, 6, 25.0)
+    st = synth.make_stereo(obj, 22, 4100)
+    K1 = pkg.init_camera_matrix_2d(obj, st.img1, (640, 480))
+    K2 = pkg.init_camera_matrix_2d(obj, st.img2, (640, 480))
+    flags = pkg.CALIB_USE_INTRINSIC_GUESS
+    objs, i1, i2 = obj, st.img1, st.img2
+    crit = (3, 60, 1e-7)
+    if case == "aspect8":
+        flags |= pkg.CALIB_FIX_ASPECT_RATIO
+    elif case == "rational12":
+        flags |= pkg.CALIB_RATIONAL_MODEL
+        crit = (3, 25, 1e-7)
+    else:
+        rng = np.random.default_rng(8)
+        keep = [np.sort(rng.choice(54, size=int(rng.integers(10, 55)), replace=False)) for _ in range(22)]
+        objs = [obj[k] for k in keep]
+        i1 = [st.img1[i][k] for i, k in enumerate(keep)]
+        i2 = [st.img2[i][k] for i, k in enumerate(keep)]
+    got = pkg.stereo_calibrate(objs, i1, i2, K1, None, K2, None, (640, 480), flags, criteria=crit)
+    ref = orc.stereo_calibrate(objs, i1, i2, K1, None, K2, None, (640, 480), flags, criteria=crit, schur=False)
+    assert abs(got["rms"] - ref["rms"]) <= REL * ref["rms"]
+    assert abs(got["iters"] - ref["iters"]) <= 1
+    tol = 1e-4 if case == "rational12" else REL       # the 8-coefficient model is nearly degenerate on this data
+    for key in ("K1", "K2", "R", "T"):
+        assert np.allclose(got[key], ref[key], rtol=tol, atol=tol * np.abs(ref[key]).max()), key
+    assert np.abs(got["rt"] - ref["rt"])[:, :3].max() < 100 * tol
+    if case == "aspect8":
+        assert got["K1"][0, 0] / got["K1"][1, 1] == pytest.approx(K1[0, 0] / K1[1, 1], rel=1e-12)
+
+
 def test_config5_shape_17x12_board_stereo_and_mono(pkg, orc, synth):
     """BASELINE config 5's shape at a size the dense oracle solves: 17x12 board (204 points per view, so
     every view spans four 64-point chunks of the fused kernel), both cameras with k1-k3, p1, p2 free."""
