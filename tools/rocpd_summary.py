@@ -47,7 +47,9 @@ def pmc(dbs, out):
 
 
 if __name__ == "__main__":
-    if sys.argv[1] == "kernels":
+    if len(sys.argv) >= 4 and sys.argv[1] == "kernels":
         kernels(sys.argv[2], sys.argv[3])
-    else:
+    elif len(sys.argv) >= 4 and sys.argv[1] == "pmc" and not sys.argv[-1].endswith(".db"):
         pmc(sys.argv[2:-1], sys.argv[-1])
+    else:
+        sys.exit(__doc__)
