@@ -368,8 +368,8 @@ __global__ __launch_bounds__(kBlock, CCALIB_VIEW_MINWAVES) void k_jac_view(PassA
 // blk contiguously; the shared block is accumulated over the wavefront's views in registers and
 // written once per wavefront (fixed assignment, so sums are bitwise reproducible).
 //
-// LDS (after the shared board): per wavefront 16 columns x RS doubles, RS >= 2*CH rows with
-// RS mod 32 in {2, 14, 18, 30} so that the 16-byte reads of 16 columns fall in disjoint banks.
+// LDS (after the shared board): per wavefront 16 columns x RS doubles, RS >= 2*CH rows, spaced so that
+// the operand reads of the matrix phase fall in disjoint banks (see fused_geom).
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(64) void k_pose_const(const double* pose, int nviews, double* pc) {
@@ -405,11 +405,12 @@ __global__ __launch_bounds__(kBlock, 3) void k_jac_fused(PassArgs a, CamParams c
     const int board_f = SHARED ? (3 * a.board_np + 3) / 4 * 4 : 0;  // floats, 16-byte granules
     double* const ldsd = reinterpret_cast<double*>(lds_dyn);  // indexed, so every access stays an LDS access
     const int cbase = board_f / 2;                             // the two shared columns (in doubles)
-    const int jt = cbase + (CONSTC ? 2 * RS : 0) + w * NPRIV * RS;  // this wavefront's buffer
+    const int WS = (NPRIV * RS + 31) & ~31;                          // doubles between the wavefronts' buffers
+    const int jt = cbase + (CONSTC ? 2 * RS : 0) + w * WS;          // this wavefront's buffer
     // after the four column buffers: one 16-double slot per wavefront through which a view's pose record
     // reaches all lanes (a dword per lane in, broadcast reads out: no vector-ALU instruction involved,
     // which matters because nothing else issues on a SIMD while an FP64 MFMA executes)
-    const int pslot = cbase + (CONSTC ? 2 * RS : 0) + kWaves * NPRIV * RS + w * kPoseConstStride;
+    const int pslot = cbase + (CONSTC ? 2 * RS : 0) + kWaves * WS + w * kPoseConstStride;
     auto slot = [&](int c) { return CONSTC && c > ICY ? c - 2 : c; };  // private column -> position in the buffer
     if constexpr (CONSTC) {
         for (int r = threadIdx.x; r < RS; r += kBlock) {
@@ -420,31 +421,43 @@ __global__ __launch_bounds__(kBlock, 3) void k_jac_fused(PassArgs a, CamParams c
     for (int c = NCOL; c < 16; c++)  // columns the set does not use stay zero
         for (int r = lane; r < RS; r += 64) ldsd[jt + slot(c) * RS + r] = 0.;
     __syncthreads();
-    // which results this lane's four accumulator registers hold: D[row][col], col = lane & 15,
-    // row = (lane >> 4) + 4 * reg
+    // The product is symmetric, so it is taken in 4x4 blocks with v_mfma_f64_4x4x4_4b_f64 (four independent
+    // blocks per instruction; A/B lane = 16 k + 4 block + i|j, result lane = 16 i + 4 block + j) and the six
+    // blocks below the diagonal are never computed.  With column groups g = 0..3 of four columns each, a lane
+    // keeps three results: D = block (g, g), E = block (g, g+1 mod 4), F = block (g, g+2) for g < 2.
     const int col = lane & 15, rq = lane >> 4;
-    int qv[4], qu[4];
+    const int ri = lane >> 4, rg = (lane >> 2) & 3, rj = lane & 3;
+    int qv[3], qu[3];
+    {
+        const int p[3] = {4 * rg + ri, 4 * rg + ri, 4 * rg + ri};
+        const int q[3] = {4 * rg + rj, 4 * ((rg + 1) & 3) + rj, 4 * ((rg + 2) & 3) + rj};
+        const bool keep[3] = {ri <= rj, true, rg < 2};
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        int row = rq + 4 * r;
-        int pc_ = col - CPOSE, pr_ = row - CPOSE;
-        qv[r] = -1, qu[r] = -1;
-        if (pc_ >= 0 && pc_ < 6) {
-            if (row < NC)
-                qv[r] = 27 + 6 * row + pc_;
-            else if (pr_ < 6 && pr_ <= pc_)
-                qv[r] = tri6(pr_, pc_);
-            else if (row == CRES)
-                qv[r] = 21 + pc_;
+        for (int r = 0; r < 3; r++) {
+            const int lo = p[r] < q[r] ? p[r] : q[r], hi = p[r] < q[r] ? q[r] : p[r];
+            qv[r] = -1, qu[r] = -1;
+            if (!keep[r]) continue;
+            if (hi < NC)
+                qu[r] = lo * NC - lo * (lo - 1) / 2 + (hi - lo);
+            else if (hi < CRES) {
+                if (lo < NC)
+                    qv[r] = 27 + 6 * lo + (hi - CPOSE);
+                else
+                    qv[r] = tri6(lo - CPOSE, hi - CPOSE);
+            } else if (hi == CRES) {
+                if (lo < NC)
+                    qu[r] = NU + lo;
+                else if (lo < CRES)
+                    qv[r] = 21 + (lo - CPOSE);
+                else
+                    qu[r] = NU + NC;
+            }
         }
-        if (row < NC && col < NC && row <= col) qu[r] = row * NC - row * (row - 1) / 2 + (col - row);
-        if (row < NC && col == CRES) qu[r] = NU + row;
-        if (row == CRES && col == CRES) qu[r] = NU + NC;
     }
-    int voff[4];  // byte offset of each register's result inside a tile of blk
+    int voff[3];  // byte offset of each result inside a tile of blk
 #pragma unroll
-    for (int r = 0; r < 4; r++) voff[r] = qv[r] >= 0 ? (qv[r] * kTileViews + w) * (int)sizeof(double) : 0x7fffffff;
-    double4_t usum = {0., 0., 0., 0.};
+    for (int r = 0; r < 3; r++) voff[r] = qv[r] >= 0 ? (qv[r] * kTileViews + w) * (int)sizeof(double) : 0x7fffffff;
+    double usum[3] = {0., 0., 0.};
     const int ntiles = (a.nviews + kTileViews - 1) / kTileViews;
     // What the wavefront needs to start on a view -- point range, this lane's image point, the pose --
     // is fetched one view ahead, between the point phase and the matrix phase of the view before,
@@ -481,18 +494,24 @@ __global__ __launch_bounds__(kBlock, 3) void k_jac_fused(PassArgs a, CamParams c
     int v = __builtin_amdgcn_readfirstlane(tile * kTileViews + w);
     bool valid = tile < ntiles && v < a.nviews;  // wave-uniform; the loop holds no workgroup barrier
     if (valid) fetch(v);
-    {   // Four stores that the range check drops.  Inside the loop the loads of a view are followed by
-        // the four result stores of the view before; giving the first view the same number of younger
-        // stores lets the wait before the point phase be "all but four" on both paths instead of "all".
+    {   // Three stores that the range check drops.  Inside the loop the loads of a view are followed by
+        // the three result stores of the view before; giving the first view the same number of younger
+        // stores lets the wait before the point phase be "all but three" on both paths instead of "all".
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
         auto none = __builtin_amdgcn_make_buffer_rsrc(blk, 0, 0, 0x00020000);
 #pragma unroll
-        for (int r = 0; r < 4; r++) __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, none, 0x7fff0000 + 64 * r + lane, 0, 0);
+        for (int r = 0; r < 3; r++) __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, none, 0x7fff0000 + 64 * r + lane, 0, 0);
     }
     const double2* const lds2r = reinterpret_cast<const double2*>(lds_dyn);
     double2* const lds2 = reinterpret_cast<double2*>(lds_dyn);
-    const int colbase = CONSTC && col == ICX ? cbase : CONSTC && col == ICY ? cbase + RS : jt + slot(col) * RS;
-    const int src = (colbase >> 1) + rq;
+    auto colbase = [&](int c) { return CONSTC && c == ICX ? cbase : CONSTC && c == ICY ? cbase + RS : jt + slot(c) * RS; };
+    // operand addresses of the first eight rows (each later group of eight is 64 bytes further on):
+    //   N  (16 bytes): column col,     rows 2rq, 2rq+1 -- the .x halves are one set of four rows, the .y the other
+    //   N1 (16 bytes): column col + 4 (mod 16), same rows
+    //   AR, BR (8 bytes): block (g, g+2) of the .x rows in the lanes of groups 0, 1, of the .y rows in groups 2, 3
+    const int srcN = (colbase(col) >> 1) + rq, srcN1 = (colbase((col + 4) & 15) >> 1) + rq;
+    const int srcA = col < 8 ? colbase(col) + 2 * rq : colbase(col - 8) + 2 * rq + 1;
+    const int srcB = col < 8 ? colbase(col + 8) + 2 * rq : colbase(col) + 2 * rq + 1;
     const int dst = (jt >> 1) + lane;  // in double2 units; RS is even
     int dirty = CH;                    // rows of points [n, dirty) hold an earlier view's values
     int npsum = 0;                     // points this wavefront has seen
@@ -534,39 +553,41 @@ __global__ __launch_bounds__(kBlock, 3) void k_jac_fused(PassArgs a, CamParams c
         }
         dirty = n;
     };
-    // Matrix phase: sixteen rows per trip.  A 16-byte LDS read gives a lane rows 8k + 2rq and 8k + 2rq + 1
-    // of column `col`, the operands of two MFMAs; the two reads of the trip after are in flight while a
-    // trip multiplies, at a fixed distance (they may run past the chunk's rows: what they fetch is then
-    // never used).  The only vector-ALU instruction of a trip is the address increment -- any other would
-    // take the SIMD away from the matrix pipe, since nothing else issues while an FP64 MFMA executes.
-    // CH is a multiple of 8, so the rows up to the next multiple of 16 exist and are zero.
-    auto matrix_phase = [&](int n, double4_t& acc, bool from_zero) {
+    // Matrix phase: eight rows per group, five instructions on five accumulators (a chain of dependent
+    // 4x4x4 MFMAs issues every 46 cycles, alternating chains every 19): diagonal blocks from (N, N), blocks
+    // (g, g+1) from (N, N1), both once for the .x and once for the .y rows, and blocks (0,2), (1,3) of both
+    // row sets in one instruction from (AR, BR).  The reads of a group are in flight while the group before
+    // multiplies (they may run past the chunk's rows: what they fetch is then never used); two register sets
+    // take turns and one address update serves two groups.  CH is a multiple of 8, so the rows up to the
+    // next multiple of 8 exist and are zero.
+    struct Acc {
+        double d0, d1, e0, e1, f;
+    };
+    auto matrix_phase = [&](int n, Acc& acc, bool from_zero) {
         __builtin_amdgcn_wave_barrier();
-        const int ntrips = (2 * n + 15) >> 4;  // >= 1
-        auto mfma4 = [&](const double2& u0, const double2& u1) {
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(u0.x, u0.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(u0.y, u0.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(u1.x, u1.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(u1.y, u1.y, acc, 0, 0, 0);
+        const int ngroups = (2 * n + 7) >> 3;  // >= 1
+        auto mfma5 = [&](const double2& u, const double2& u1, double ar, double br) {
+            acc.d0 = __builtin_amdgcn_mfma_f64_4x4x4f64(u.x, u.x, acc.d0, 0, 0, 0);
+            acc.e0 = __builtin_amdgcn_mfma_f64_4x4x4f64(u.x, u1.x, acc.e0, 0, 0, 0);
+            acc.f = __builtin_amdgcn_mfma_f64_4x4x4f64(ar, br, acc.f, 0, 0, 0);
+            acc.d1 = __builtin_amdgcn_mfma_f64_4x4x4f64(u.y, u.y, acc.d1, 0, 0, 0);
+            acc.e1 = __builtin_amdgcn_mfma_f64_4x4x4f64(u.y, u1.y, acc.e1, 0, 0, 0);
         };
-        // two register sets take turns (no copies); the first trip starts the chain from zero
-        int a = src + 8;
-        double2 p0 = lds2r[src], p1 = lds2r[src + 4];
-        double2 q0 = lds2r[a], q1 = lds2r[a + 4];
-        __builtin_amdgcn_sched_barrier(0);
-        if (from_zero) acc = double4_t{0., 0., 0., 0.};  // the chain's first link then takes a literal zero
-        mfma4(p0, p1);
-        for (int k = 1; k < ntrips;) {
-            a += 8;
-            p0 = lds2r[a], p1 = lds2r[a + 4];
+        int oN = srcN, oN1 = srcN1, oA = srcA, oB = srcB;
+        double2 pn = lds2r[oN], pn1 = lds2r[oN1];
+        double pa = ldsd[oA], pb = ldsd[oB];
+        if (from_zero) acc = Acc{0., 0., 0., 0., 0.};
+        for (int g = 0; g < ngroups; g += 2) {
+            const double2 qn = lds2r[oN + 4], qn1 = lds2r[oN1 + 4];
+            const double qa = ldsd[oA + 8], qb = ldsd[oB + 8];
             __builtin_amdgcn_sched_barrier(0);
-            mfma4(q0, q1);
-            if (++k >= ntrips) break;
-            a += 8;
-            q0 = lds2r[a], q1 = lds2r[a + 4];
+            mfma5(pn, pn1, pa, pb);
+            if (g + 1 >= ngroups) break;
+            oN += 8, oN1 += 8, oA += 16, oB += 16;
+            pn = lds2r[oN], pn1 = lds2r[oN1];
+            pa = ldsd[oA], pb = ldsd[oB];
             __builtin_amdgcn_sched_barrier(0);
-            mfma4(p0, p1);
-            ++k;
+            mfma5(qn, qn1, qa, qb);
         }
         __builtin_amdgcn_wave_barrier();  // the reads are done before the buffer is overwritten
     };
@@ -580,7 +601,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_jac_fused(PassArgs a, CamParams c
     while (valid) {
         const int tile_cur = tile, vfirst = first, vnp = np;
         npsum += vnp;
-        double4_t acc = {0., 0., 0., 0.};
+        Acc acc = {0., 0., 0., 0., 0.};
         if constexpr (!MULTI) {  // the launcher guarantees np <= CH <= 64
             point_phase(vnp, mpt, bX, bY, bZ);
             advance();
@@ -607,26 +628,27 @@ __global__ __launch_bounds__(kBlock, 3) void k_jac_fused(PassArgs a, CamParams c
                 if (last && valid) spread_pose();
             }
         }
-        usum += acc;
-        // Unconditional buffer stores: lanes whose register holds nothing to keep carry an offset
+        // the two row sets of D and E, and the two halves of F (lanes 8 apart in a row of 16), are summed here
+        const double res[3] = {acc.d0 + acc.d1, acc.e0 + acc.e1, acc.f + dpp_move<0x128>(acc.f)};
+#pragma unroll
+        for (int r = 0; r < 3; r++) usum[r] += res[r];
+        // Unconditional buffer stores: lanes whose result is not kept carry an offset
         // past the tile, which the range check drops.  (Stores under a branch would hide their
         // number from the wait-count bookkeeping and make the next view wait for all of them.)
         auto rsrc = __builtin_amdgcn_make_buffer_rsrc(blk + (size_t)tile_cur * NB * kTileViews, 0,
                                                       NB * kTileViews * (int)sizeof(double), 0x00020000);
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
+        for (int r = 0; r < 3; r++) {
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-            double d = acc[r];
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, d), rsrc, voff[r], 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, res[r]), rsrc, voff[r], 0, 0);
         }
     }
     double* po = part + (size_t)(blockIdx.x * kWaves + w) * NR;
+    // a sum of ones (the principal-point columns against themselves): the point count
+    const bool ones = CONSTC && ri == rj && (4 * rg + ri == ICX || 4 * rg + ri == ICY);
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int row = rq + 4 * r;
-        const bool ones = CONSTC && row == col && (col == ICX || col == ICY);  // a sum of ones: the point count
-        if (qu[r] >= 0) po[qu[r]] = ones ? (double)npsum : usum[r];
-    }
+    for (int r = 0; r < 3; r++)
+        if (qu[r] >= 0) po[qu[r]] = r == 0 && ones ? (double)npsum : usum[r];
 }
 
 // ---- per-view elimination --------------------------------------------------------------------
@@ -908,13 +930,17 @@ void launch_pose_const(const double* pose, int nviews, double* pc, hipStream_t s
 FusedGeom fused_geom(int maxnp, bool shared_board, int board_np, bool const_cols) {
     FusedGeom g;
     g.CH = maxnp >= 64 ? 64 : (maxnp + 7) / 8 * 8;
-    g.RS = 2 * g.CH;
-    while (!(g.RS % 32 == 2 || g.RS % 32 == 14 || g.RS % 32 == 18 || g.RS % 32 == 30)) g.RS += 2;
+    // Banks are 4 bytes wide, 64 of them for the 8- and 16-byte reads of the matrix phase, which the LDS
+    // serves in lane groups of 32 and 16.  With RS = 4 (mod 8) doubles between columns and a multiple of 32
+    // doubles between the wavefronts' buffers, all four operand reads of a group of rows are conflict-free
+    // in every wavefront (column c, column c + 4, and the two half-and-half reads of columns c, c +- 8).
+    g.RS = 2 * g.CH + 4;
     size_t board_f = shared_board ? (size_t)(3 * board_np + 3) / 4 * 4 : 0;
     // 14 private columns per wavefront + 2 shared ones when the principal point is in the set, else 16;
-    // then one pose-record slot per wavefront
-    g.lds_bytes = (unsigned)(sizeof(float) * board_f + sizeof(double) * (const_cols ? kWaves * 14 + 2 : kWaves * 16) * (size_t)g.RS +
-                             sizeof(double) * kWaves * kPoseConstStride);
+    // then one pose-record slot per wavefront, and room for the reads that run ahead past the last column
+    const size_t ws = ((size_t)(const_cols ? 14 : 16) * g.RS + 31) / 32 * 32;
+    g.lds_bytes = (unsigned)(sizeof(float) * board_f + sizeof(double) * ((const_cols ? 2 : 0) * (size_t)g.RS + kWaves * ws) +
+                             sizeof(double) * kWaves * kPoseConstStride + 128);
     return g;
 }
 
