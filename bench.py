@@ -37,11 +37,11 @@ FLOPS_RESIDUAL = 54
 # The fused kernel does not exploit the zeros: it multiplies the dense 16-column row matrix on the
 # FP64 matrix pipe (ceil(2P/16)*4 instructions of 16x16x4 per view) after ~156 vector FP64
 # instructions per point.  Executed flops are reported beside the algorithmic ones.
-MFMA_FLOPS = 2 * 16 * 16 * 4
+MFMA_FLOPS = 2 * 4 * (4 * 4 * 4)     # v_mfma_f64_4x4x4_4b_f64: four 4x4x4 blocks
 BYTES_JAC_VIEW = (8 * 54 + 104 + 8 * (21 + 6 + 6 * 9)) / 54.0   # image points + pose record in, blocks out, per point
 PEAK_FP64_TFLOPS = 78.6    # MI355X dense FP64, matrix and vector alike (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
 PEAK_HBM_GBPS = 8000.0
-PROFILE_PMC = os.path.join(ROOT, "profiles", "r01_bench_hbm_pmc_v7.json")   # rocprofv3 FETCH_SIZE / WRITE_SIZE passes
+PROFILE_PMC = os.path.join(ROOT, "profiles", "r01_bench_hbm_pmc_v8.json")   # rocprofv3 FETCH_SIZE / WRITE_SIZE passes
 
 
 def parse():
@@ -156,7 +156,8 @@ def main():
         flops_alg = FLOPS_JAC_PASS if fused else FLOPS_JAC_VIEW
         achieved_tf = flops_alg * points_local / t_jac / 1e12
         P = int(obj.shape[0])
-        executed = (-(-2 * P // 16) * 4 * MFMA_FLOPS + 2 * 156 * P) / P if fused else None
+        # five block instructions per eight rows of A (ten of the sixteen 4x4 blocks of the symmetric product)
+        executed = (-(-2 * P // 8) * 5 * MFMA_FLOPS + 2 * 156 * P) / P if fused else None
         traffic = None
         try:   # per-launch HBM bytes from the committed counter passes (FETCH_SIZE doubled, as gfx950 needs)
             pm = json.load(open(PROFILE_PMC))
@@ -178,7 +179,7 @@ def main():
             "hbm_frac": round(BYTES_JAC_VIEW * points_local / t_jac / 1e9 / PEAK_HBM_GBPS, 4),
             "other_kernels_ms": {"k_jac_shared": round(km["jac_shared"], 4), "k_err_wave": round(km["err"], 4)},
             "note": "FP64 path: the normal-equation update of a view is one A^T A product on the FP64 matrix pipe "
-                    "(v_mfma_f64_16x16x4), whose dense peak equals the FP64 vector peak on this part; achieved counts "
+                    "(v_mfma_f64_4x4x4_4b, upper-triangle blocks only), whose dense peak equals the FP64 vector peak on this part; achieved counts "
                     "the zero-exploiting algorithmic flops (oracle/flopcount.py), executed_* what the kernel issues",
         }
         # the same pass on the vector ALU alone (two kernels, zero-exploiting accumulation), for comparison
