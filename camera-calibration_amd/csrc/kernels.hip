@@ -84,7 +84,7 @@ struct Lane {
 
 __device__ __forceinline__ void stage_board(const PassArgs& a) {
     if (a.shared_board) {
-        for (int i = threadIdx.x; i < 3 * a.board_np; i += kBlock) lds_dyn[i] = a.obj[i];
+        for (int i = threadIdx.x; i < 3 * a.board_np; i += blockDim.x) lds_dyn[i] = a.obj[i];
         __syncthreads();
     }
 }
@@ -384,15 +384,20 @@ __global__ __launch_bounds__(64) void k_pose_const(const double* pose, int nview
     for (int k = 0; k < 16; k++) pc[kPoseConstStride * (size_t)v + k] = rec[k];
 }
 
-template <class M, bool SHARED, bool MULTI>
-__global__ __launch_bounds__(kBlock, 3) void k_jac_fused(PassArgs a, CamParams cp, const int* __restrict__ off,
+// TPB tiles per workgroup (4 TPB wavefronts): the per-workgroup part of the LDS (board, shared columns) is
+// paid once, so where three one-tile workgroups do not fit a CU one three-tile workgroup still does.
+template <class M, bool SHARED, bool MULTI, int TPB>
+__global__ __launch_bounds__(kBlock * TPB, TPB == 1 ? 3 : 1) void k_jac_fused(PassArgs a, CamParams cp, const int* __restrict__ off,
                                                          const double* __restrict__ pc, double* __restrict__ blk,
                                                          double* __restrict__ part, int RS, int CH) {
     constexpr int NC = M::NC, NB = M::NBLK, NU = M::NU, NR = M::NRED_U;
     constexpr int CPOSE = NC, CRES = NC + 6, NCOL = NC + 7;
     static_assert(NCOL <= 16, "column set does not fit one 16x16 tile");
     static_assert(kWaves == kTileViews, "one wavefront per view of a tile");
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // the wavefront's number within the workgroup, as a scalar: tile numbers and the loop condition derived
+    // from it must stay wave-uniform for the compiler, or the view loop turns into masked vector control flow
+    const int lane = threadIdx.x & 63, wl = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int w = wl & (kWaves - 1), tb = wl / kWaves;          // view of the tile, tile of the workgroup
     stage_board(a);
     // The principal-point columns are the same for every view -- (1, 0) and (0, 1) down the rows -- so
     // when the set has both they are kept once per workgroup instead of once per wavefront; with 14
@@ -406,14 +411,14 @@ __global__ __launch_bounds__(kBlock, 3) void k_jac_fused(PassArgs a, CamParams c
     double* const ldsd = reinterpret_cast<double*>(lds_dyn);  // indexed, so every access stays an LDS access
     const int cbase = board_f / 2;                             // the two shared columns (in doubles)
     const int WS = (NPRIV * RS + 31) & ~31;                          // doubles between the wavefronts' buffers
-    const int jt = cbase + (CONSTC ? 2 * RS : 0) + w * WS;          // this wavefront's buffer
+    const int jt = cbase + (CONSTC ? 2 * RS : 0) + wl * WS;         // this wavefront's buffer
     // after the four column buffers: one 16-double slot per wavefront through which a view's pose record
     // reaches all lanes (a dword per lane in, broadcast reads out: no vector-ALU instruction involved,
     // which matters because nothing else issues on a SIMD while an FP64 MFMA executes)
-    const int pslot = cbase + (CONSTC ? 2 * RS : 0) + kWaves * WS + w * kPoseConstStride;
+    const int pslot = cbase + (CONSTC ? 2 * RS : 0) + TPB * kWaves * WS + wl * kPoseConstStride;
     auto slot = [&](int c) { return CONSTC && c > ICY ? c - 2 : c; };  // private column -> position in the buffer
     if constexpr (CONSTC) {
-        for (int r = threadIdx.x; r < RS; r += kBlock) {
+        for (int r = threadIdx.x; r < RS; r += kBlock * TPB) {
             ldsd[cbase + r] = (r & 1) ? 0. : 1.;
             ldsd[cbase + RS + r] = (r & 1) ? 1. : 0.;
         }
@@ -490,7 +495,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_jac_fused(PassArgs a, CamParams c
     if constexpr (SHARED) {
         if (lane < a.board_np) bX = lds_dyn[3 * lane], bY = lds_dyn[3 * lane + 1], bZ = lds_dyn[3 * lane + 2];
     }
-    int tile = blockIdx.x;
+    int tile = blockIdx.x * TPB + tb;
     int v = __builtin_amdgcn_readfirstlane(tile * kTileViews + w);
     bool valid = tile < ntiles && v < a.nviews;  // wave-uniform; the loop holds no workgroup barrier
     if (valid) fetch(v);
@@ -592,7 +597,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_jac_fused(PassArgs a, CamParams c
         __builtin_amdgcn_wave_barrier();  // the reads are done before the buffer is overwritten
     };
     auto advance = [&]() {  // the next view's loads go out ahead of the matrix phase
-        tile += gridDim.x;
+        tile += gridDim.x * TPB;
         v = __builtin_amdgcn_readfirstlane(tile * kTileViews + w);
         valid = tile < ntiles && v < a.nviews;
         if (valid) fetch(v);
@@ -643,7 +648,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_jac_fused(PassArgs a, CamParams c
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, res[r]), rsrc, voff[r], 0, 0);
         }
     }
-    double* po = part + (size_t)(blockIdx.x * kWaves + w) * NR;
+    double* po = part + (size_t)((blockIdx.x * TPB + tb) * kWaves + w) * NR;
     // a sum of ones (the principal-point columns against themselves): the point count
     const bool ones = CONSTC && ri == rj && (4 * rg + ri == ICX || 4 * rg + ri == ICY);
 #pragma unroll
@@ -829,9 +834,20 @@ static void launch_jac_fused(const PassArgs& a, const CamParams& cp, const doubl
                              hipStream_t st) {
     constexpr bool const_cols = M::index_of(I_CX) >= 0 && M::index_of(I_CY) == M::index_of(I_CX) + 1;
     FusedGeom g = fused_geom(a.maxnp, a.shared_board != 0, a.board_np, const_cols);
+    // `grid` counts tiles in flight.  Three one-tile workgroups per CU if their LDS allows it; otherwise, if it
+    // fits, one three-tile workgroup (above the 64 KB default limit of dynamic LDS: raised per function).
+    const FusedGeom g3 = fused_geom(a.maxnp, a.shared_board != 0, a.board_np, const_cols, 3);
+    bool three = 3 * ((g.lds_bytes + 511u) / 512u * 512u) > kLdsPerCU && g3.lds_bytes <= kLdsPerCU && grid % 3 == 0;
+    if (const char* e = std::getenv("CCALIB_FUSED_TPB")) three = std::atoi(e) == 3 && g3.lds_bytes <= kLdsPerCU && grid % 3 == 0;
     auto go = [&](auto shared, auto multi) {
-        k_jac_fused<M, decltype(shared)::value, decltype(multi)::value>
-            <<<dim3(grid), dim3(kBlock), g.lds_bytes, st>>>(a, cp, a.off, pc, blk, part, g.RS, g.CH);
+        if (three) {
+            auto f = k_jac_fused<M, decltype(shared)::value, decltype(multi)::value, 3>;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g3.lds_bytes);
+            f<<<dim3(grid / 3), dim3(3 * kBlock), g3.lds_bytes, st>>>(a, cp, a.off, pc, blk, part, g.RS, g.CH);
+        } else {
+            k_jac_fused<M, decltype(shared)::value, decltype(multi)::value, 1>
+                <<<dim3(grid), dim3(kBlock), g.lds_bytes, st>>>(a, cp, a.off, pc, blk, part, g.RS, g.CH);
+        }
     };
     using T = std::true_type;
     using F = std::false_type;
@@ -927,7 +943,7 @@ void launch_pose_const(const double* pose, int nviews, double* pc, hipStream_t s
     hipLaunchKernelGGL(k_pose_const, dim3((nviews + 63) / 64), dim3(64), 0, st, pose, nviews, pc);
 }
 
-FusedGeom fused_geom(int maxnp, bool shared_board, int board_np, bool const_cols) {
+FusedGeom fused_geom(int maxnp, bool shared_board, int board_np, bool const_cols, int tiles) {
     FusedGeom g;
     g.CH = maxnp >= 64 ? 64 : (maxnp + 7) / 8 * 8;
     // Banks are 4 bytes wide, 64 of them for the 8- and 16-byte reads of the matrix phase, which the LDS
@@ -939,8 +955,8 @@ FusedGeom fused_geom(int maxnp, bool shared_board, int board_np, bool const_cols
     // 14 private columns per wavefront + 2 shared ones when the principal point is in the set, else 16;
     // then one pose-record slot per wavefront, and room for the reads that run ahead past the last column
     const size_t ws = ((size_t)(const_cols ? 14 : 16) * g.RS + 31) / 32 * 32;
-    g.lds_bytes = (unsigned)(sizeof(float) * board_f + sizeof(double) * ((const_cols ? 2 : 0) * (size_t)g.RS + kWaves * ws) +
-                             sizeof(double) * kWaves * kPoseConstStride + 128);
+    g.lds_bytes = (unsigned)(sizeof(float) * board_f + sizeof(double) * ((const_cols ? 2 : 0) * (size_t)g.RS + tiles * kWaves * ws) +
+                             sizeof(double) * tiles * kWaves * kPoseConstStride + 128);
     return g;
 }
 

@@ -40,7 +40,9 @@ struct FusedGeom {
     int CH, RS;
     unsigned lds_bytes;
 };
-FusedGeom fused_geom(int maxnp, bool shared_board, int board_np, bool const_cols = true);
+// LDS geometry of the fused Jacobian kernel for workgroups of `tiles` tiles (4 wavefronts each)
+FusedGeom fused_geom(int maxnp, bool shared_board, int board_np, bool const_cols = true, int tiles = 1);
+constexpr unsigned kLdsPerCU = 160 * 1024;
 
 struct DeltaC {
     double v[I_NMODEL];  // step of the kernel's intrinsic columns (0 for columns not optimised)
