@@ -946,6 +946,9 @@ void launch_pose_const(const double* pose, int nviews, double* pc, hipStream_t s
 FusedGeom fused_geom(int maxnp, bool shared_board, int board_np, bool const_cols, int tiles) {
     FusedGeom g;
     g.CH = maxnp >= 64 ? 64 : (maxnp + 7) / 8 * 8;
+    // longer views go in chunks; chunks of 56 points leave room for twelve wavefronts per CU instead of eight,
+    // and are taken when they do not add a chunk
+    if (maxnp > 64 && (maxnp + 55) / 56 <= (maxnp + 63) / 64) g.CH = 56;
     // Banks are 4 bytes wide, 64 of them for the 8- and 16-byte reads of the matrix phase, which the LDS
     // serves in lane groups of 32 and 16.  With RS = 4 (mod 8) doubles between columns and a multiple of 32
     // doubles between the wavefronts' buffers, all four operand reads of a group of rows are conflict-free
