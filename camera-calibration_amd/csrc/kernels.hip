@@ -401,7 +401,7 @@ __global__ __launch_bounds__(kBlock * TPB, TPB == 1 ? 3 : 1) void k_jac_fused(Pa
     stage_board(a);
     // The principal-point columns are the same for every view -- (1, 0) and (0, 1) down the rows -- so
     // when the set has both they are kept once per workgroup instead of once per wavefront; with 14
-    // instead of 16 private columns three workgroups fit a CU.  Their rows never read as zero past
+    // instead of 16 private columns twelve wavefronts fit a CU.  Their rows never read as zero past
     // a view's last point, which only spoils the two sums of ones U(cx,cx), U(cy,cy): those are
     // replaced by the exact point count when the wavefront stores its shared-block sums.
     constexpr int ICX = M::index_of(I_CX), ICY = M::index_of(I_CY);

@@ -619,7 +619,7 @@ int ccalib_solver_create(ccalib_solver** out, int device, int ncams, int nviews,
     s->grid_view = (nviews + views_per_block - 1) / views_per_block;
     s->grid_red = std::min(s->grid_view, 512);
     if (const char* e = std::getenv("CCALIB_GRID_RED")) s->grid_red = std::max(1, std::min(s->grid_view, std::atoi(e)));
-    s->grid_fused = std::min((nviews + kTileViews - 1) / kTileViews, 768);  // three workgroups per CU
+    s->grid_fused = std::min((nviews + kTileViews - 1) / kTileViews, 768);  // tiles in flight: three per CU
     if (const char* e = std::getenv("CCALIB_GRID_FUSED"))
         s->grid_fused = std::max(1, std::min((nviews + kTileViews - 1) / kTileViews, std::atoi(e)));
     if (const char* e = std::getenv("CCALIB_NO_FUSED")) s->use_fused = std::atoi(e) == 0;
