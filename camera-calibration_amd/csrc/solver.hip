@@ -622,6 +622,7 @@ int ccalib_solver_create(ccalib_solver** out, int device, int ncams, int nviews,
     s->grid_fused = std::min((nviews + kTileViews - 1) / kTileViews, 768);  // tiles in flight: three per CU
     if (const char* e = std::getenv("CCALIB_GRID_FUSED"))
         s->grid_fused = std::max(1, std::min((nviews + kTileViews - 1) / kTileViews, std::atoi(e)));
+    s->grid_fused = (s->grid_fused + 2) / 3 * 3;  // a workgroup may own three tiles; tiles past the last view do nothing
     if (const char* e = std::getenv("CCALIB_NO_FUSED")) s->use_fused = std::atoi(e) == 0;
     s->grid_err = std::min((nviews + 3) / 4, 2048);  // eight wavefronts per SIMD
     if (const char* e = std::getenv("CCALIB_NO_AHEAD")) s->speculate = std::atoi(e) == 0;
