@@ -840,11 +840,12 @@ static void launch_jac_fused(const PassArgs& a, const CamParams& cp, const doubl
     bool three = 3 * ((g.lds_bytes + 511u) / 512u * 512u) > kLdsPerCU && g3.lds_bytes <= kLdsPerCU && grid % 3 == 0;
     if (const char* e = std::getenv("CCALIB_FUSED_TPB")) three = std::atoi(e) == 3 && g3.lds_bytes <= kLdsPerCU && grid % 3 == 0;
     auto go = [&](auto shared, auto multi) {
-        if (three) {
-            auto f = k_jac_fused<M, decltype(shared)::value, decltype(multi)::value, 3>;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g3.lds_bytes);
-            f<<<dim3(grid / 3), dim3(3 * kBlock), g3.lds_bytes, st>>>(a, cp, a.off, pc, blk, part, g.RS, g.CH);
+        auto f3 = k_jac_fused<M, decltype(shared)::value, decltype(multi)::value, 3>;
+        if (three && hipFuncSetAttribute(reinterpret_cast<const void*>(f3), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)g3.lds_bytes) == hipSuccess) {
+            f3<<<dim3(grid / 3), dim3(3 * kBlock), g3.lds_bytes, st>>>(a, cp, a.off, pc, blk, part, g.RS, g.CH);
         } else {
+            if (three) (void)hipGetLastError();  // the refused attribute must not surface as a launch error later
             k_jac_fused<M, decltype(shared)::value, decltype(multi)::value, 1>
                 <<<dim3(grid), dim3(kBlock), g.lds_bytes, st>>>(a, cp, a.off, pc, blk, part, g.RS, g.CH);
         }
