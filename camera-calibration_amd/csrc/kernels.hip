@@ -570,6 +570,9 @@ __global__ __launch_bounds__(kBlock * TPB, TPB == 1 ? 3 : 1) void k_jac_fused(Pa
     };
     auto matrix_phase = [&](int n, Acc& acc, bool from_zero) {
         __builtin_amdgcn_wave_barrier();
+        // The point phase is one long chain of dependent FP64 instructions, the matrix phase independent work
+        // that fills any gap: the wavefront issues at low priority here and at high priority outside.
+        __builtin_amdgcn_s_setprio(0);
         const int ngroups = (2 * n + 7) >> 3;  // >= 1
         auto mfma5 = [&](const double2& u, const double2& u1, double ar, double br) {
             acc.d0 = __builtin_amdgcn_mfma_f64_4x4x4f64(u.x, u.x, acc.d0, 0, 0, 0);
@@ -594,6 +597,7 @@ __global__ __launch_bounds__(kBlock * TPB, TPB == 1 ? 3 : 1) void k_jac_fused(Pa
             __builtin_amdgcn_sched_barrier(0);
             mfma5(qn, qn1, qa, qb);
         }
+        __builtin_amdgcn_s_setprio(3);
         __builtin_amdgcn_wave_barrier();  // the reads are done before the buffer is overwritten
     };
     auto advance = [&]() {  // the next view's loads go out ahead of the matrix phase
