@@ -35,8 +35,8 @@ FLOPS_JAC_PASS = 556       # whole Jacobian pass in one sweep: projection + Jaco
 FLOPS_JAC_VIEW = 428       # the per-view-block part alone (the two-kernel path for rational models)
 FLOPS_RESIDUAL = 54
 # The fused kernel does not exploit the zeros: it multiplies the dense 16-column row matrix on the
-# FP64 matrix pipe (ceil(2P/16)*4 instructions of 16x16x4 per view) after ~156 vector FP64
-# instructions per point.  Executed flops are reported beside the algorithmic ones.
+# FP64 matrix pipe (upper-triangle 4x4 blocks: ceil(2P/8)*5 instructions of 4x4x4_4b per view) after
+# ~156 vector FP64 instructions per point.  Executed flops are reported beside the algorithmic ones.
 MFMA_FLOPS = 2 * 4 * (4 * 4 * 4)     # v_mfma_f64_4x4x4_4b_f64: four 4x4x4 blocks
 BYTES_JAC_VIEW = (8 * 54 + 104 + 8 * (21 + 6 + 6 * 9)) / 54.0   # image points + pose record in, blocks out, per point
 PEAK_FP64_TFLOPS = 78.6    # MI355X dense FP64, matrix and vector alike (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)

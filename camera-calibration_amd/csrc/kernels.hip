@@ -9,7 +9,7 @@
 //   * k_jac_fused   the whole Jacobian pass of a camera for column sets of up to nine intrinsics:
 //                   one wavefront per view, one lane per point; the normal-equation update is the
 //                   product A^T A of the view's row matrix A = [Ji | Je | e], accumulated by
-//                   v_mfma_f64_16x16x4_f64 from a per-wave LDS buffer (see the kernel's comment);
+//                   v_mfma_f64_4x4x4_4b_f64 block by block from a per-wave LDS buffer (see the kernel's comment);
 //   * the G-lane kernels: a view is owned by G consecutive lanes of one wavefront (G = 2..64, power
 //     of two); lane g handles points g, g+G, ...; image points are read in the caller's own layout
 //     (view-major float2), so the G lanes of a view read one contiguous run:
@@ -360,17 +360,16 @@ __global__ __launch_bounds__(kBlock, CCALIB_VIEW_MINWAVES) void k_jac_view(PassA
 //   A^T A = [ U    W    gc  ]
 //           [ W^T  V    ge  ]
 //           [ gc^T ge^T err ]
-// which v_mfma_f64_16x16x4_f64 accumulates four rows of A at a time.  One wavefront owns one view
+// which the FP64 matrix pipe accumulates in 4x4 blocks, upper triangle only.  One wavefront owns one view
 // at a time: lane p evaluates point p (residual, intrinsic columns, pose columns), writes its two
 // rows of A into a per-wave LDS buffer stored column-major, and the wavefront then streams the
-// buffer through the MFMA (the A and B operands are the same register: the product is symmetric).
-// A workgroup owns one tile of kTileViews = 4 views (one per wavefront) and writes that tile of
-// blk contiguously; the shared block is accumulated over the wavefront's views in registers and
-// written once per wavefront (fixed assignment, so sums are bitwise reproducible).
+// buffer through the MFMAs.  Four wavefronts own one tile of kTileViews = 4 views and write that tile of
+// blk contiguously (a workgroup holds one tile or three); the shared block is accumulated over the
+// wavefront's views in registers and written once per wavefront (fixed assignment, so sums are bitwise
+// reproducible).
 //
 // LDS (after the shared board): per wavefront 16 columns x RS doubles, RS >= 2*CH rows, spaced so that
 // the operand reads of the matrix phase fall in disjoint banks (see fused_geom).
-typedef double double4_t __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(64) void k_pose_const(const double* pose, int nviews, double* pc) {
     int v = blockIdx.x * 64 + threadIdx.x;
@@ -412,7 +411,7 @@ __global__ __launch_bounds__(kBlock * TPB, TPB == 1 ? 3 : 1) void k_jac_fused(Pa
     const int cbase = board_f / 2;                             // the two shared columns (in doubles)
     const int WS = (NPRIV * RS + 31) & ~31;                          // doubles between the wavefronts' buffers
     const int jt = cbase + (CONSTC ? 2 * RS : 0) + wl * WS;         // this wavefront's buffer
-    // after the four column buffers: one 16-double slot per wavefront through which a view's pose record
+    // after the column buffers: one 16-double slot per wavefront through which a view's pose record
     // reaches all lanes (a dword per lane in, broadcast reads out: no vector-ALU instruction involved,
     // which matters because nothing else issues on a SIMD while an FP64 MFMA executes)
     const int pslot = cbase + (CONSTC ? 2 * RS : 0) + TPB * kWaves * WS + wl * kPoseConstStride;
