@@ -651,12 +651,24 @@ __global__ __launch_bounds__(kBlock * TPB, TPB == 1 ? 3 : 1) void k_jac_fused(Pa
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, res[r]), rsrc, voff[r], 0, 0);
         }
     }
-    double* po = part + (size_t)((blockIdx.x * TPB + tb) * kWaves + w) * NR;
+    // The four wavefronts of a tile slot add their shared-block sums through LDS (each into its own, now idle,
+    // column buffer) and the first of them writes one row of `part` per tile slot, in a fixed order.
     // a sum of ones (the principal-point columns against themselves): the point count
     const bool ones = CONSTC && ri == rj && (4 * rg + ri == ICX || 4 * rg + ri == ICY);
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int r = 0; r < 3; r++)
-        if (qu[r] >= 0) po[qu[r]] = r == 0 && ones ? (double)npsum : usum[r];
+    for (int r = 0; r < 3; r++) ldsd[jt + 64 * r + lane] = r == 0 && ones ? (double)npsum : usum[r];
+    __syncthreads();
+    if (w == 0) {
+        double* po = part + (size_t)(blockIdx.x * TPB + tb) * NR;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            double s = 0;
+#pragma unroll
+            for (int ww = 0; ww < kWaves; ww++) s += ldsd[jt + ww * WS + 64 * r + lane];
+            if (qu[r] >= 0) po[qu[r]] = s;
+        }
+    }
 }
 
 // ---- per-view elimination --------------------------------------------------------------------

@@ -309,7 +309,7 @@ int enqueue_jac(ccalib_solver* s, int buf, double lambda_hint, int ofs, JacLayou
         CamParams cp = cam_params(s->intr[c], s->aspect[c]);
         PassArgs a = pass_args(s, c, cam_pose(s, c));
         if (m->jac_fused && s->use_fused) {
-            int rows = s->grid_fused * kTileViews;
+            int rows = s->grid_fused;  // one row of partial sums per tile slot
             PART_TAKE(part, s, (size_t)rows * m->NRED_U);
             double* pc = c == 0 ? s->d_pc : s->d_pc3;
             bool& fresh = c == 0 ? s->pc_fresh : s->pc3_fresh;
