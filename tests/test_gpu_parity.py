@@ -387,6 +387,25 @@ def test_full_size_100k_views_properties(pkg, synth):
     assert abs(rms2 - rms) < 1e-5 * rms
 
 
+def test_one_and_three_tile_workgroups_agree_bitwise(pkg, synth, monkeypatch):
+    """The fused Jacobian kernel runs with one or three tiles per workgroup depending on what fits a CU; the
+    assignment of views to wavefronts and the order of every sum are the same, so the results must be too."""
+    obj = synth.chessboard(9, 6, 25.0)
+    ms = synth.make_views(obj, 20_003, 31337)
+    intr, mask, aspect, rt = _start(pkg, synth, ms)
+    outs = []
+    for tpb in ("1", "3"):
+        monkeypatch.setenv("CCALIB_FUSED_TPB", tpb)
+        s = pkg.Solver(obj, ms.img)
+        s.set_start(intr, mask, rt)
+        st = s.run(criteria=(3, 12, 1e-12))
+        outs.append((st["iters"], s.get()))
+        s.close()
+    (it1, o1), (it3, o3) = outs
+    assert it1 == it3
+    assert np.array_equal(o1["intr"], o3["intr"]) and np.array_equal(o1["rt"], o3["rt"]) and o1["err"] == o3["err"]
+
+
 def test_noise_free_recovery_10k_views(pkg, synth):
     obj = synth.chessboard(9, 6, 25.0)
     ms = synth.make_views(obj, 10_000, 4242, noise=0.0)
