@@ -283,8 +283,14 @@ def cpu_baseline(ge, synth, obj, nviews, seed, pkg):
                                  nthreads=nth)
         dt = time.perf_counter() - t0
         res[label] = nviews * obj.shape[0] * r["jac_passes"] / dt
+    # the same sample, start and iteration count through the HIP path: RMS and intrinsics against the oracle's
+    g = pkg.calibrate_camera(obj, ms.img, (640, 480), K=K0, dist=cam.dist(5) * 0.8, ndist=5,
+                             flags=pkg.CALIB_USE_INTRINSIC_GUESS, criteria=(3, 5, 0.0), init_rt=rt0)
     return {"value": res["all"], "unit": "points/s", "cores": ncores, "kind": "port",
             "single_core_value": res["1"],
+            "rms_oracle": float(r["rms"]), "rms_hip": float(g["rms"]),
+            "rms_rel_delta": abs(float(g["rms"]) - float(r["rms"])) / float(r["rms"]),
+            "K_rel_delta": float(np.abs(g["K"] - r["K"]).max() / np.abs(r["K"]).max()),
             "sample": f"first {nviews} views of the same set, 5 LM iterations, Schur-eliminated restatement of the "
                       f"OpenCV 4.1.0 algorithm (oracle/), OpenMP over views; OpenCV itself is not installed and its "
                       f"dense (18+6N)^2 solve does not scale to this size"}
