@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("CCALIB_LIB") or os.path.join(_HERE, "libccalib.so")  
 SYMBOLS = [
     "ccalib_last_error", "ccalib_version",
     "ccalib_calibrate_camera", "ccalib_stereo_calibrate", "ccalib_reprojection_error",
+    "ccalib_reprojection_error_noalloc",
     "ccalib_init_camera_matrix_2d", "ccalib_write_mono_yaml", "ccalib_write_stereo_yaml",
     "ccalib_solver_create", "ccalib_solver_destroy", "ccalib_solver_set_start",
     "ccalib_rccl_unique_id", "ccalib_solver_use_rccl", "ccalib_solver_use_callback",

@@ -195,8 +195,11 @@ __global__ __launch_bounds__(kBlock) void k_err_wave(PassArgs a, CamParams cp, c
 
 // ---- projectPoints + per-view squared error (the reference's RMS re-check, monocular_circle.cpp:5-29) ----
 template <bool RAT, int G>
-__global__ __launch_bounds__(kBlock) void k_reproj(PassArgs a, CamParams cp, float2* proj, double* view_err) {
+__global__ __launch_bounds__(kBlock) void k_reproj(PassArgs a, CamParams cp, float2* proj, double* view_err,
+                                                   const int* __restrict__ bad) {
     using M = Model<0u, false, RAT>;
+    // set by a preceding kernel that found the view table inconsistent: nothing may be read through it then
+    if (bad && *bad) return;
     stage_board(a);
     Lane<G> l(a);
     for (; l.v0 < a.nviews; l.next_round()) {
@@ -934,13 +937,13 @@ void launch_err_wave(const PassArgs& a, const CamParams& cp, bool rational, cons
 }
 
 void launch_reproj(const PassArgs& a, const CamParams& cp, bool rational, int grid, float2* proj, double* view_err,
-                   hipStream_t st) {
+                   hipStream_t st, const int* bad) {
     dispatch_G(a.G, [&](auto g) {
         constexpr int GG = decltype(g)::value;
         if (rational)
-            k_reproj<true, GG><<<dim3(grid), dim3(kBlock), a.lds_bytes, st>>>(a, cp, proj, view_err);
+            k_reproj<true, GG><<<dim3(grid), dim3(kBlock), a.lds_bytes, st>>>(a, cp, proj, view_err, bad);
         else
-            k_reproj<false, GG><<<dim3(grid), dim3(kBlock), a.lds_bytes, st>>>(a, cp, proj, view_err);
+            k_reproj<false, GG><<<dim3(grid), dim3(kBlock), a.lds_bytes, st>>>(a, cp, proj, view_err, bad);
     });
 }
 

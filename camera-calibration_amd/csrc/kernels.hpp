@@ -77,9 +77,10 @@ const ModelOps* find_model(unsigned need_mask, bool aspect, bool need_rational);
 // sum of squared residuals from pose records (pc: nviews x kPoseConstStride), one wavefront per view
 void launch_err_wave(const PassArgs&, const CamParams&, bool rational, const double* pc, int grid, double* part,
                      hipStream_t);
-// projected pixels (as float, optional) and the squared reprojection error of every view
+// projected pixels (as float, optional) and the squared reprojection error of every view; a non-null `bad`
+// points at a device word which, when non-zero, makes the kernel return at once
 void launch_reproj(const PassArgs&, const CamParams&, bool rational, int grid, float2* proj, double* view_err,
-                   hipStream_t);
+                   hipStream_t, const int* bad = nullptr);
 // One launch reduces the partial-result tables of a whole pass (see k_colsum).
 struct ColsumSeg {
     const double* part;

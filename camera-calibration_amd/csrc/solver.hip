@@ -386,6 +386,7 @@ void parse_jac(const ccalib_solver* s, const JacLayout& L, double* U, double* gs
 int be_jac(void* user, const double* shared, double lambda_hint, double* U, double* gs, double* err) {
     ccalib_solver* s = (ccalib_solver*)user;
     s->t_enter = std::chrono::steady_clock::now();
+    (void)hipGetLastError();  // an error another HIP user of this thread left behind is not ours to report
     const int ns = s->ns();
     if (s->steps_since_jac > 0) s->level_accepted[s->last_level] = true;  // the driver moved on: that step was accepted
     s->steps_since_jac = 0;
@@ -419,6 +420,7 @@ int be_jac(void* user, const double* shared, double lambda_hint, double* U, doub
 int be_reduce(void* user, double lambda, const int* fidx, int nf, double* Ssum, double* bsum) {
     ccalib_solver* s = (ccalib_solver*)user;
     s->t_enter = std::chrono::steady_clock::now();
+    (void)hipGetLastError();  // an error another HIP user of this thread left behind is not ours to report
     int kc = s->kcols(), nsum = kc * (kc + 1) / 2 + kc;
     if (!(s->have_cached && s->cached_lambda == lambda)) {
         int rc = enqueue_schur(s, s->cur, lambda, 0);
@@ -454,6 +456,7 @@ int be_step_err(void* user, double lambda, double lambda_next, const int* fidx, 
                 const double* shared_new, double* dnorm2, double* pnorm2, double* err) {
     ccalib_solver* s = (ccalib_solver*)user;
     s->t_enter = std::chrono::steady_clock::now();
+    (void)hipGetLastError();  // an error another HIP user of this thread left behind is not ours to report
     int rc;
     const int cur = s->cur;
     std::vector<double> dfull(s->ns(), 0.);
@@ -831,6 +834,7 @@ int ccalib_solver_init_poses(ccalib_solver* s, int cam, const double* K, const d
         HIP_TRY(hipMalloc(&s->d_parked_state, sizeof(double) * kParkedDoubles * (size_t)s->nviews));
     }
     Parked parked{s->d_parked_view + s->nviews, s->d_parked_view, s->d_parked_state};
+    (void)hipGetLastError();  // an error another HIP user of this thread left behind is not ours to report
     launch_init_pose(a, cp, rational, dst, s->d_status, parked, s->stream);
     HIP_TRY(hipGetLastError());
     std::vector<int> status(s->nviews);
@@ -942,6 +946,8 @@ int ccalib_solver_num_shared(ccalib_solver* s, int* ns) {
 int ccalib_solver_eval_error(ccalib_solver* s, double* err) {
     if (!s || !s->started || !err) return set_error(CCALIB_ERR_STATE, "eval_error before set_start");
     HIP_TRY(hipSetDevice(s->device));
+    (void)hipGetLastError();  // an error another HIP user of this thread left behind is not ours to report
+    s->t_enter = std::chrono::steady_clock::now();
     int rc;
     if ((rc = stereo_compose(s, false, s->cur))) return rc;
     for (int c = 0; c < s->ncams; c++) {
@@ -1089,3 +1095,179 @@ int ccalib_reprojection_error(int nviews, const int* npts, const float* obj_xyz,
 }
 
 }  // extern "C"
+
+// ---- reprojection error without any allocation ------------------------------------------------
+// ccalib_reprojection_error_noalloc: the pass of ccalib_reprojection_error for callers that cannot allocate
+// (code under HIP graph capture, serving loops).  Everything the pass needs beyond the caller's inputs and
+// outputs -- the prefix offsets of the views, the poses in the (r|t) rows the kernel reads, the per-view squared
+// errors, a validity word -- lives in one file-scope device array per GPU.
+namespace {
+
+constexpr int kNoAllocMaxViews = 65536;
+// byte offsets inside the scratch array
+constexpr size_t kNaOff = 0;                                                        // int[kNoAllocMaxViews + 1]
+constexpr size_t kNaBad = (sizeof(int) * (kNoAllocMaxViews + 1) + 255) / 256 * 256; // int
+constexpr size_t kNaPose = kNaBad + 256;                                            // double[kNoAllocMaxViews][6]
+constexpr size_t kNaErr = kNaPose + sizeof(double) * 6 * kNoAllocMaxViews;          // double[kNoAllocMaxViews]
+constexpr size_t kNoAllocScratchBytes = kNaErr + sizeof(double) * kNoAllocMaxViews; // about 3.9 MB
+
+// Every GPU the library runs on holds its own copy of this array, at its own address, until the process ends.
+// Host code never uses the name below as a pointer: scratch_for_current_device() asks the runtime for the array's
+// device address once per device, and that address is what kernels, memsets and copies receive.
+static __device__ __align__(256) unsigned char scratch[kNoAllocScratchBytes];
+
+constexpr int kMaxDevices = 64;
+unsigned char* g_scratch_ptr[kMaxDevices] = {nullptr};
+std::atomic<bool> g_scratch_known[kMaxDevices];
+
+int scratch_for_current_device(unsigned char** out) {
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return set_error(CCALIB_ERR_ARG, "device %d is beyond the %d this entry point tracks", dev, kMaxDevices);
+    if (!g_scratch_known[dev].load(std::memory_order_acquire)) {
+        unsigned char* p = nullptr;
+        HIP_TRY(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch)));
+        if (!p) return set_error(CCALIB_ERR_HIP, "hipGetSymbolAddress returned no address for the scratch array");
+        g_scratch_ptr[dev] = p;  // two threads racing here store the same address
+        g_scratch_known[dev].store(true, std::memory_order_release);
+    }
+    *out = g_scratch_ptr[dev];
+    return CCALIB_OK;
+}
+
+constexpr int kNaBlock = 1024;
+
+// One workgroup: exclusive prefix sum of the point counts into off[0..nviews], the poses as (r|t) rows, and the
+// validity word: a view with fewer than 4 or more than max_npts points, or a total beyond `capacity`, makes the
+// whole table invalid (the later kernels then read nothing through it).
+__global__ __launch_bounds__(kNaBlock) void k_na_prepare(const int* __restrict__ npts, int nviews, int max_npts, int capacity,
+                                                         const double* __restrict__ rvecs, const double* __restrict__ tvecs,
+                                                         int* off, int* bad, double* pose) {
+    __shared__ long long part[kNaBlock];
+    __shared__ int any_bad;
+    const int t = threadIdx.x;
+    if (t == 0) any_bad = 0;
+    __syncthreads();
+    const int per = (nviews + kNaBlock - 1) / kNaBlock;
+    const int lo = min(t * per, nviews), hi = min(lo + per, nviews);
+    long long sum = 0;
+    bool mine_bad = false;
+    for (int i = lo; i < hi; i++) {
+        const int n = npts[i];
+        mine_bad = mine_bad || n < 4 || n > max_npts;
+        sum += n > 0 ? n : 0;
+    }
+    part[t] = sum;
+    if (mine_bad) any_bad = 1;
+    __syncthreads();
+    // inclusive scan of the per-thread sums (Hillis-Steele; 10 rounds)
+    for (int d = 1; d < kNaBlock; d <<= 1) {
+        long long add = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += add;
+        __syncthreads();
+    }
+    const long long total = part[kNaBlock - 1];
+    const bool invalid = any_bad != 0 || total > (long long)capacity;
+    long long run = t > 0 ? part[t - 1] : 0;
+    for (int i = lo; i < hi; i++) {
+        off[i] = invalid ? 0 : (int)run;
+        run += npts[i] > 0 ? npts[i] : 0;
+    }
+    if (t == 0) {
+        off[nviews] = invalid ? 0 : (int)total;
+        *bad = invalid ? 1 : 0;
+    }
+    for (int i = t; i < 3 * nviews; i += kNaBlock) {
+        const int v = i / 3, k = i - 3 * v;
+        pose[6 * (size_t)v + k] = rvecs[i];
+        pose[6 * (size_t)v + 3 + k] = tvecs[i];
+    }
+}
+
+// One workgroup: per-view RMS and the global RMS = sqrt(sum of squared errors / sum of points), summed in a fixed
+// order; NaN everywhere when the table was invalid.
+__global__ __launch_bounds__(kNaBlock) void k_na_finish(const int* __restrict__ off, const int* __restrict__ bad,
+                                                        const double* __restrict__ verr, int nviews, double* per_view_rms,
+                                                        double* total_rms) {
+    __shared__ double sm[kNaBlock];
+    const int t = threadIdx.x;
+    const bool invalid = *bad != 0;
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    double s = 0;
+    for (int i = t; i < nviews; i += kNaBlock) {
+        const double e = invalid ? nan : verr[i];
+        s += e;
+        if (per_view_rms) per_view_rms[i] = invalid ? nan : sqrt(e / (double)(off[i + 1] - off[i]));
+    }
+    sm[t] = s;
+    __syncthreads();
+    for (int h = kNaBlock / 2; h > 0; h >>= 1) {
+        if (t < h) sm[t] += sm[t + h];
+        __syncthreads();
+    }
+    if (t == 0 && total_rms) *total_rms = invalid ? nan : sqrt(sm[0] / (double)off[nviews]);
+}
+
+}  // namespace
+
+extern "C" int ccalib_reprojection_error_noalloc(int nviews, const int* d_npts, int max_npts, int capacity,
+                                                 const float* d_obj_xyz, const float* d_img_uv, const double* K,
+                                                 const double* dist, int ndist, const double* d_rvecs,
+                                                 const double* d_tvecs, float* d_proj_uv, double* d_per_view_rms,
+                                                 double* d_total_rms, void* stream) {
+    if (nviews < 1 || !d_npts || !d_obj_xyz || !d_img_uv || !K || !d_rvecs || !d_tvecs || ndist < 0 || ndist > 14 ||
+        (ndist && !dist) || max_npts < 4 || capacity < 4 || (!d_proj_uv && !d_per_view_rms && !d_total_rms))
+        return set_error(CCALIB_ERR_ARG, "reprojection_error_noalloc: bad arguments");
+    if (nviews > kNoAllocMaxViews)
+        return set_error(CCALIB_ERR_ARG, "reprojection_error_noalloc: %d views exceed the %d the static scratch buffer holds",
+                         nviews, kNoAllocMaxViews);
+    if ((long long)max_npts > (long long)capacity)
+        return set_error(CCALIB_ERR_ARG, "reprojection_error_noalloc: max_npts %d exceeds the capacity %d", max_npts, capacity);
+    for (int i = 8; i < ndist; i++)
+        if (dist[i] != 0.) return set_error(CCALIB_ERR_UNSUPPORTED, "thin-prism / tilted coefficients are not built into this library");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return set_error(CCALIB_ERR_NO_DEVICE, "no HIP device is usable (this library has no CPU path)");
+    unsigned char* base = nullptr;
+    int rc = scratch_for_current_device(&base);
+    if (rc) return rc;
+    int* off = reinterpret_cast<int*>(base + kNaOff);
+    int* bad = reinterpret_cast<int*>(base + kNaBad);
+    double* pose = reinterpret_cast<double*>(base + kNaPose);
+    double* verr = reinterpret_cast<double*>(base + kNaErr);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    (void)hipGetLastError();  // an error another HIP user of this thread left behind is not ours to report
+
+    // the same launch geometry ccalib_reprojection_error gets from its solver (views with their own object points)
+    PassArgs a;
+    a.img = reinterpret_cast<const float2*>(d_img_uv);
+    a.obj = d_obj_xyz;
+    a.off = off;
+    a.pose = pose;
+    a.nviews = nviews;
+    a.shared_board = 0;
+    a.board_np = 0;
+    a.maxnp = max_npts;
+    a.G = choose_G(nviews, max_npts, false, 0);
+    a.staged = 1;
+    if (a.G) {
+        a.lds_bytes = (unsigned)pass_lds_bytes(a.G, max_npts, false, 0);
+    } else {
+        a.G = 64, a.staged = 0, a.lds_bytes = 0;
+    }
+    const int views_per_block = pass_block_size() / a.G;
+    const int grid = (nviews + views_per_block - 1) / views_per_block;
+    double intr[18] = {K[0], K[4], K[2], K[5]};
+    for (int i = 0; i < ndist && i < 8; i++) intr[4 + i] = dist[i];
+    const CamParams cp = cam_params(intr, 0.);
+    const bool rational = intr[9] != 0. || intr[10] != 0. || intr[11] != 0.;
+
+    hipLaunchKernelGGL(k_na_prepare, dim3(1), dim3(kNaBlock), 0, st, d_npts, nviews, max_npts, capacity, d_rvecs, d_tvecs, off,
+                       bad, pose);
+    launch_reproj(a, cp, rational, grid, reinterpret_cast<float2*>(d_proj_uv), verr, st, bad);
+    if (d_per_view_rms || d_total_rms)
+        hipLaunchKernelGGL(k_na_finish, dim3(1), dim3(kNaBlock), 0, st, off, bad, verr, nviews, d_per_view_rms, d_total_rms);
+    HIP_TRY(hipGetLastError());
+    return CCALIB_OK;
+}

@@ -124,6 +124,30 @@ int ccalib_reprojection_error(int nviews, const int* npts, const float* obj_xyz,
                               const double* tvecs, float* proj_uv, double* per_view_rms,
                               double* total_rms);
 
+/*
+ * The pass of ccalib_reprojection_error as an entry point that allocates nothing.  It has no counterpart in the
+ * reference: it exists for callers that cannot allocate device memory -- code under HIP graph capture, serving
+ * loops, harnesses that forbid hipMalloc.  It calls no hipMalloc / hipFree / stream or event creation; its working
+ * storage (view offsets, (r|t) pose rows, per-view squared errors, a validity word) is one static device array of
+ * about 3.9 MB per GPU, which every GPU the library runs on holds until the process ends.
+ *   Every array argument whose name starts with d_ is a DEVICE pointer on the current device; K (3x3) and
+ *   dist[ndist] are host pointers, read before the call returns.
+ *   d_npts[nviews]     points per view (>= 4 each), nviews <= 65536 (more is rejected with CCALIB_ERR_ARG)
+ *   max_npts           an upper bound of every d_npts[i];  capacity = points the three point arrays hold
+ *   d_obj_xyz, d_img_uv  capacity x 3 / capacity x 2 floats, view after view;  d_rvecs, d_tvecs  nviews x 3 doubles
+ *   d_proj_uv (optional, capacity x 2 floats), d_per_view_rms (optional, nviews), d_total_rms (optional, 1)
+ *   stream             a hipStream_t (NULL = the default stream); the work is enqueued there and the call returns
+ *                      without waiting, so the outputs are valid once that stream reaches this point
+ * A point count outside [4, max_npts] or a total beyond `capacity` is found on the device: d_per_view_rms and
+ * d_total_rms then receive NaN, d_proj_uv is left untouched and nothing is read past the stated sizes.
+ * All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two threads) race;
+ * calls enqueued on one stream are ordered and safe.
+ */
+int ccalib_reprojection_error_noalloc(int nviews, const int* d_npts, int max_npts, int capacity,
+                                      const float* d_obj_xyz, const float* d_img_uv, const double* K,
+                                      const double* dist, int ndist, const double* d_rvecs, const double* d_tvecs,
+                                      float* d_proj_uv, double* d_per_view_rms, double* d_total_rms, void* stream);
+
 /* cv::initCameraMatrix2D (binocular_chessboard.cpp:147-148).  K out, 3x3. */
 int ccalib_init_camera_matrix_2d(int nviews, const int* npts, const float* obj_xyz,
                                  const float* img_uv, int width, int height, double aspect,

@@ -3,6 +3,12 @@ import sys
 
 import pytest
 
+# torch ships its own copy of the HIP runtime.  Imported before libccalib.so is loaded, the library binds to that
+# copy (same SONAME) and the process holds ONE runtime; loaded the other way round the process holds two, and a
+# stream created by one (torch.cuda.Stream) is an invalid argument to the other.  Tests that hand torch streams
+# or tensors to the library need the single-runtime order, so it is fixed here for the whole session.
+import torch  # noqa: F401,E402
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
