@@ -42,6 +42,9 @@ BYTES_JAC_VIEW = (8 * 54 + 104 + 8 * (21 + 6 + 6 * 9)) / 54.0   # image points +
 PEAK_FP64_TFLOPS = 78.6    # MI355X dense FP64, matrix and vector alike (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
 PEAK_HBM_GBPS = 8000.0
 PROFILE_PMC = os.path.join(ROOT, "profiles", "r01_bench_hbm_pmc_v12.json")   # rocprofv3 FETCH_SIZE / WRITE_SIZE passes
+# stereoCalibrate with the reference's flag set: per camera fy cx cy k1 k2 k6 free, fx tied, rational model
+# (oracle/flopcount.py, stereo_reference_flags_6col_per_camera); a point pair is one point in each camera
+FLOPS_STEREO_PER_CAMERA_POINT = 473
 
 
 def parse():
@@ -159,17 +162,24 @@ def main():
         # five block instructions per eight rows of A (ten of the sixteen 4x4 blocks of the symmetric product)
         executed = (-(-2 * P // 8) * 5 * MFMA_FLOPS + 2 * 156 * P) / P if fused else None
         traffic = None
-        try:   # per-launch HBM bytes from the committed counter passes (FETCH_SIZE doubled, as gfx950 needs)
+        traffic_source = None
+        try:   # per-launch HBM bytes from the committed counter passes (FETCH_SIZE doubled, as gfx950 needs):
+            # counters cannot be read inside this run, so the figure is only given for the configuration it was
+            # taken on, and labelled as what it is
+            if not (V == 100_000 and obj.shape[0] == 54):
+                raise ValueError("profile taken at 100k views of a 9x6 board")
             pm = json.load(open(PROFILE_PMC))
             for name, c in pm.items():
                 if name.startswith("k_jac_fused" if fused else "k_jac_view"):
                     traffic = int((2 * c["FETCH_SIZE"]["mean_per_launch"] + c["WRITE_SIZE"]["mean_per_launch"]) * 1024)
+                    traffic_source = ("committed rocprofv3 --pmc passes (%s), same kernel and configuration; "
+                                      "not measured in this run" % os.path.relpath(PROFILE_PMC, ROOT))
         except (OSError, KeyError, ValueError):
             pass
         roofline = {
             "bound": "mfma", "kernel": "k_jac_fused" if fused else "k_jac_view", "achieved": round(achieved_tf, 3),
             "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved_tf / PEAK_FP64_TFLOPS, 4),
-            "traffic": traffic,
+            "traffic": traffic, "traffic_source": traffic_source,
             "launch_ms": round(km["jac_view"], 4),
             "algorithmic_flops_per_point": flops_alg,
             "executed_flops_per_point": round(executed, 1) if executed else None,
@@ -201,10 +211,12 @@ def main():
         roofline["valu_only_path"] = valu
         cpu = None
         whole = None
+        stereo = None
         if not args.no_cpu and world == 1:   # the CPU leg and the whole-call leg are timed at N = 1 only
             cpu = cpu_baseline(ge, synth, obj, args.cpu_views, seed, pkg)
             cpu["opencv"] = opencv_check(pkg, synth)
             whole = whole_call(pkg, obj, ms)
+            stereo = stereo_block(pkg, synth, local_rank, args.steps, args.warmup)
         result = {
             "metric": "residual+Jacobian point evaluations/s in the calibrateCamera LM loop (%s, 9x6 board)"
                       % (f"{args.views // 1000}k views/GPU" if args.scaling == "weak" else f"{args.views // 1000}k views in total"),
@@ -219,7 +231,7 @@ def main():
             "lm_iters_per_sec": args.steps / dt,
             "projected_points_per_sec": points_total * (st["jac_passes"] + st["err_passes"]) / dt,
             "jac_passes": st["jac_passes"], "err_passes": st["err_passes"], "rms_px": rms,
-            "roofline": roofline, "cpu_baseline": cpu, "whole_call": whole,
+            "roofline": roofline, "cpu_baseline": cpu, "whole_call": whole, "stereo": stereo,
         }
     solver.close()
     if dist is not None:
@@ -227,6 +239,57 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))
+
+
+def stereo_block(pkg, synth, dev, steps, warmup):
+    """The stereoCalibrate LM loop (binocular_chessboard.cpp:152-162: its flag set, 9x6 board) on one GPU with the
+    pairs resident in HBM: BASELINE configs[2] (10 000 pairs) and, because that size is bound by launch and host
+    latencies rather than by the kernels, the same problem at 100 000 pairs.  A step is one LM iteration (both
+    cameras' Jacobian passes, the per-view rewrite and elimination, the 18x18 reduced solve, back-substitution,
+    and the residual passes of rejected trial steps)."""
+    obj = synth.chessboard(9, 6, 25.0)
+    P = int(obj.shape[0])
+    out = {}
+    for label, pairs in (("configs[2]: 10k pairs", 10_000), ("100k pairs", 100_000)):
+        st = synth.make_stereo(obj, pairs, 0xC0FFEE + 3)
+        K = [pkg.init_camera_matrix_2d(obj, im[:2000], (640, 480)) for im in (st.img1, st.img2)]
+        intr = np.zeros((2, 18))
+        for c in range(2):      # CALIB_SAME_FOCAL_LENGTH averages the two guesses, as cvStereoCalibrateImpl does
+            intr[c, :4] = [(K[0][0, 0] + K[1][0, 0]) / 2, (K[0][1, 1] + K[1][1, 1]) / 2,
+                           (K[0][0, 2] + K[1][0, 2]) / 2, (K[0][1, 2] + K[1][1, 2]) / 2]
+        mask = np.zeros((2, 18), dtype=np.uint8)
+        mask[:, [1, 2, 3, 4, 5, 11]] = 1
+        aspect = [intr[0, 0] / intr[0, 1], intr[1, 0] / intr[1, 1]]
+        rt0 = synth.perturbed_poses(st.rvec, st.tvec, 3, rot_sigma=0.01, trans_sigma=3.0)
+        lr0 = np.r_[st.r_lr, st.t_lr] + np.array([1e-3, -1e-3, 5e-4, 0.5, -0.2, 0.3])
+        s = pkg.Solver(obj, st.img1, st.img2, device=dev)
+        s.set_start(intr, mask, rt0, aspect=aspect, same_focal=True, lr=lr0)
+        if warmup > 0:
+            s.run(criteria=(3, warmup, 0.0))
+        s.set_start(intr, mask, rt0, aspect=aspect, same_focal=True, lr=lr0)
+        t0 = time.perf_counter()
+        stt = s.run(criteria=(3, steps, 0.0))
+        dt = time.perf_counter() - t0
+        res = s.get()
+        km = s.time_kernels(reps=50)      # camera 0's fused Jacobian kernel alone, HIP events on the solver's stream
+        s.close()
+        t_jac = km["jac_view"] * 1e-3
+        tf = FLOPS_STEREO_PER_CAMERA_POINT * pairs * P / t_jac / 1e12
+        out[label] = {
+            "pairs": pairs, "points_per_view": P, "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4),
+            "lm_iters_per_sec": round(steps / dt, 1),
+            "point_pairs_per_sec": pairs * P * stt["jac_passes"] / dt,
+            "jac_passes": stt["jac_passes"], "err_passes": stt["err_passes"],
+            "rms_px": float(np.sqrt(res["err"] / (2.0 * pairs * P))),
+            "roofline": {"bound": "mfma", "kernel": "k_jac_fused (6 columns, one launch per camera)",
+                         "launch_ms": round(km["jac_view"], 4), "achieved": round(tf, 3), "peak": PEAK_FP64_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(tf / PEAK_FP64_TFLOPS, 4),
+                         "algorithmic_flops_per_camera_point": FLOPS_STEREO_PER_CAMERA_POINT, "traffic": None},
+        }
+    out["note"] = ("stereoCalibrate LM loop, flags FIX_ASPECT_RATIO+ZERO_TANGENT_DIST+USE_INTRINSIC_GUESS+SAME_FOCAL_LENGTH+"
+                   "RATIONAL_MODEL+FIX_K3+FIX_K4+FIX_K5, one GPU, pairs resident in HBM; a point pair is one board point "
+                   "seen by both cameras")
+    return out
 
 
 def whole_call(pkg, obj, ms):
@@ -286,8 +349,26 @@ def cpu_baseline(ge, synth, obj, nviews, seed, pkg):
     # the same sample, start and iteration count through the HIP path: RMS and intrinsics against the oracle's
     g = pkg.calibrate_camera(obj, ms.img, (640, 480), K=K0, dist=cam.dist(5) * 0.8, ndist=5,
                              flags=pkg.CALIB_USE_INTRINSIC_GUESS, criteria=(3, 5, 0.0), init_rt=rt0)
+    # The dense restatement (the full (18+6N)^2 normal matrix solved whole, as OpenCV 4.1.0 does), one core, at the
+    # sizes it can reach: all of configs[0], and a 64-view sample of configs[1] (3 iterations; the oracle's Jacobi
+    # SVD of the 402x402 system dominates -- cv::solve(DECOMP_SVD) is the reference's default there)
+    dense = {}
+    m0 = synth.make_views(obj, 20, 0xC0FFEE + 1)
+    t0 = time.perf_counter()
+    r0 = orc.calibrate_camera(obj, m0.img, (640, 480), schur=False)
+    dt0 = time.perf_counter() - t0
+    dense["configs[0]"] = {"points_per_s": 20 * obj.shape[0] * r0["jac_passes"] / dt0, "ms": round(dt0 * 1e3, 1),
+                           "iters": r0["iters"], "unknowns": 18 + 6 * 20, "solve": "SVD"}
+    grid = synth.asymmetric_circles(8, 11, 12.5)
+    m1 = synth.make_views(grid, 100, 0xC0FFEE + 2)
+    for name, nv, fl in (("configs[1] sample, SVD", 64, 0), ("configs[1] sample, LU", 100, orc.USE_LU)):
+        t0 = time.perf_counter()
+        r1 = orc.calibrate_camera(grid, m1.img[:nv], (640, 480), criteria=(3, 3, 0.0), schur=False, flags=fl)
+        dt1 = time.perf_counter() - t0
+        dense[name] = {"points_per_s": nv * grid.shape[0] * r1["jac_passes"] / dt1, "ms": round(dt1 * 1e3, 1),
+                       "views": nv, "iters": r1["iters"], "unknowns": 18 + 6 * nv}
     return {"value": res["all"], "unit": "points/s", "cores": ncores, "kind": "port",
-            "single_core_value": res["1"],
+            "single_core_value": res["1"], "dense_one_core": dense,
             "rms_oracle": float(r["rms"]), "rms_hip": float(g["rms"]),
             "rms_rel_delta": abs(float(g["rms"]) - float(r["rms"])) / float(r["rms"]),
             "K_rel_delta": float(np.abs(g["K"] - r["K"]).max() / np.abs(r["K"]).max()),

@@ -220,6 +220,88 @@ def count():
     return out
 
 
+def count_model(cols, aspect=False, rational=False):
+    """Single-sweep Jacobian pass of one point for an arbitrary column set of the 12-coefficient model, in the
+    kernels' factored formulation.  cols: names out of fx fy cx cy k1 k2 p1 p2 k3 k4 k5 k6; aspect: fx = fy * a and
+    the fy column carries (xd * a, yd); rational: the denominator 1 + k4 r^2 + k5 r^4 + k6 r^6 is evaluated."""
+    global FLOPS
+    R = [C(v) for v in (0.9, -0.1, 0.2, 0.1, 0.95, -0.15, -0.2, 0.1, 0.97)]
+    t = [C(10.0), C(-20.0), C(600.0)]
+    dR = [[C(0.1 * (i + j + 1)) for i in range(9)] for j in range(3)]
+    fy, cx, cy, asp = C(805.0), C(320.0), C(240.0), C(1.01)
+    k = [C(-0.28), C(0.09), C(5e-4), C(-3e-4), C(-0.01), C(0.01), C(0.02), C(0.03)]   # k1 k2 p1 p2 k3 k4 k5 k6
+    X, Y, u, v = C(50.0), C(75.0), C(400.0), C(300.0)
+    Z, O = C(0, zero=True), C(1, one=True)
+    fx = fy * asp if aspect else C(800.0)
+    # intrinsic columns: charged per requested column (the products shared between them once)
+    charged = {"fx": 0, "fy": 1 if aspect else 0, "cx": 0, "cy": 0, "k1": 2, "k2": 2, "p1": 2, "p2": 2, "k3": 2,
+               "k4": 2, "k5": 2, "k6": 2}
+    col_flops = sum(charged[c] for c in cols)
+    shared = 0
+    if any(c in cols for c in ("k1", "k2", "k3", "k4", "k5", "k6")):
+        shared += 4 if rational else 2       # qx = fx x ic, qy = fy y ic
+    if any(c in cols for c in ("k4", "k5", "k6")):
+        shared += 2                          # wx = -qx g, wy = -qy g
+    FLOPS = 0
+    xc = R[0] * X + R[1] * Y + t[0]
+    yc = R[3] * X + R[4] * Y + t[1]
+    zc = R[6] * X + R[7] * Y + t[2]
+    z = 1.0 / zc
+    x, y = xc * z, yc * z
+    r2 = x * x + y * y
+    r4 = r2 * r2
+    r6 = r4 * r2
+    a1 = 2 * x * y
+    a2 = r2 + 2 * x * x
+    a3 = r2 + 2 * y * y
+    cdist = 1 + k[0] * r2 + k[1] * r4 + k[4] * r6
+    ic = 1.0 / (1 + k[5] * r2 + k[6] * r4 + k[7] * r6) if rational else O
+    g = cdist * ic
+    xd = x * g + k[2] * a1 + k[3] * a2
+    yd = y * g + k[2] * a3 + k[3] * a1
+    ex = xd * fx + cx - u
+    ey = yd * fy + cy - v
+    projection = FLOPS + (1 if aspect else 0)
+    FLOPS = 0
+    gp = (k[0] + 2 * k[1] * r2 + 3 * k[4] * r4) * ic
+    if rational:
+        gp = gp - cdist * ic * ic * (k[5] + 2 * k[6] * r2 + 3 * k[7] * r4)
+    D00 = g + 2 * x * x * gp + 2 * k[2] * y + 6 * k[3] * x
+    D01 = a1 * gp + 2 * k[2] * x + 2 * k[3] * y
+    D11 = g + 2 * y * y * gp + 6 * k[2] * y + 2 * k[3] * x
+    sx, sy = fx * z, fy * z
+    Tx = [sx * D00, sx * D01, None]
+    Ty = [sy * D01, sy * D11, None]
+    Tx[2] = -(Tx[0] * x + Tx[1] * y)
+    Ty[2] = -(Ty[0] * x + Ty[1] * y)
+    jex, jey = [None] * 6, [None] * 6
+    for j in range(3):
+        d = dR[j]
+        dX, dY, dZ = d[0] * X + d[1] * Y, d[3] * X + d[4] * Y, d[6] * X + d[7] * Y
+        jex[j] = Tx[0] * dX + Tx[1] * dY + Tx[2] * dZ
+        jey[j] = Ty[0] * dX + Ty[1] * dY + Ty[2] * dZ
+        jex[3 + j], jey[3 + j] = Tx[j], Ty[j]
+    pose_cols = FLOPS
+    qx, qy = fx * x * ic, fy * y * ic
+    wx, wy = (-(qx * g), -(qy * g)) if rational else (Z, Z)
+    col = {"fx": (xd, Z), "fy": ((xd * asp) if aspect else Z, yd), "cx": (O, Z), "cy": (Z, O),
+           "k1": (qx * r2, qy * r2), "k2": (qx * r4, qy * r4), "p1": (fx * a1, fy * a3), "p2": (fx * a2, fy * a1),
+           "k3": (qx * r6, qy * r6), "k4": (wx * r2, wy * r2), "k5": (wx * r4, wy * r4), "k6": (wx * r6, wy * r6)}
+    jx = [col[c][0] for c in cols]
+    jy = [col[c][1] for c in cols]
+    FLOPS = 0
+    accumulate_shared(jx, jy, ex, ey)
+    accumulate_view(jx, jy, jex, jey, ex, ey)
+    accumulation = FLOPS
+    return {"projection": projection, "intrinsic_columns": col_flops + shared, "pose_columns": pose_cols,
+            "accumulation": accumulation, "total": projection + col_flops + shared + pose_cols + accumulation}
+
+
 if __name__ == "__main__":
-    print(json.dumps(count(), indent=1))
+    out = count()
+    out["mono_flags0_9col"] = count_model(["fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3"])
+    # the reference's stereoCalibrate flag set, per camera: fy cx cy k1 k2 k6 with fx tied, rational model
+    out["stereo_reference_flags_6col_per_camera"] = count_model(["fy", "cx", "cy", "k1", "k2", "k6"], aspect=True,
+                                                                rational=True)
+    print(json.dumps(out, indent=1))
     _ = math.pi

@@ -560,8 +560,12 @@ double orc_stereo_calibrate(int nviews, const int* npts, const double* obj, cons
         memcpy(lm.param + 6, init_rt, sizeof(double) * 6 * nviews);
     } else {
         double* RT0 = (double*)malloc(sizeof(double) * 6 * nviews);
-        for (int i = 0, ofs = 0; i < nviews; ofs += npts[i], i++) {
-            int ni = npts[i];
+        int* ofs0 = (int*)malloc(sizeof(int) * nviews);
+        for (int i = 0, pos = 0; i < nviews; pos += npts[i], i++) ofs0[i] = pos;
+        int nth0 = (schur && nthreads > 0) ? nthreads : 1;
+#pragma omp parallel for num_threads(nth0) schedule(dynamic, 16)
+        for (int i = 0; i < nviews; i++) {
+            int ni = npts[i], ofs = ofs0[i];
             double om[2][3], r[2][9], t[2][3];
             for (int k = 0; k < 2; k++) {
                 orc_find_extrinsic(ni, obj + (size_t)ofs * 3, imgs[k] + (size_t)ofs * 2, Ak[k], dk[k], om[k], t[k]);
@@ -584,6 +588,7 @@ double orc_stereo_calibrate(int nviews, const int* npts, const double* obj, cons
                 RT0[i + nviews * (3 + a)] = Tref[a];
             }
         }
+        free(ofs0);
         for (int i = 0; i < 6; i++) {
             qsort(RT0 + i * nviews, nviews, sizeof(double), dbl_cmp);
             lm.param[i] = nviews % 2 != 0 ? RT0[i * nviews + nviews / 2]
@@ -616,10 +621,15 @@ double orc_stereo_calibrate(int nviews, const int* npts, const double* obj, cons
         lm.user = &ss;
     }
 
-    double* err = (double*)malloc(sizeof(double) * maxPoints * 2);
-    double* Je = (double*)malloc(sizeof(double) * maxPoints * 2 * 6);
-    double* J_LR = (double*)malloc(sizeof(double) * maxPoints * 2 * 6);
-    double* Ji = (double*)calloc((size_t)maxPoints * 2 * NI, sizeof(double));
+    /* the schur path walks the views in parallel: per-thread row buffers and shared-block accumulators
+     * (the dense, OpenCV-shaped path writes one big matrix and stays on one thread) */
+    int nth = (schur && nthreads > 0) ? nthreads : 1;
+    const size_t rowbuf = (size_t)maxPoints * 2 * (1 + 6 + 6 + NI);
+    double* scratch = (double*)calloc((size_t)nth * rowbuf, sizeof(double));
+    const size_t nacc = (size_t)ns * ns + ns + 1;
+    double* Uacc = (double*)calloc((size_t)nth * nacc, sizeof(double));
+    int* vofs = (int*)malloc(sizeof(int) * nviews);
+    for (int i = 0, pos = 0; i < nviews; pos += npts[i], i++) vofs[i] = pos;
     double reprojErr = 0;
     int jac_passes = 0, err_passes = 0;
 
@@ -654,9 +664,21 @@ double orc_stereo_calibrate(int nviews, const int* npts, const double* obj, cons
             }
         }
         if (calcJ && schur) schur_zero(&ss);
+        memset(Uacc, 0, sizeof(double) * (size_t)nth * nacc);
         int n = lm.nparams;
-        for (int i = 0, ofs = 0; i < nviews; ofs += npts[i], i++) {
-            int ni = npts[i];
+#pragma omp parallel for num_threads(nth) schedule(static)
+        for (int i = 0; i < nviews; i++) {
+            int tid = 0;
+#ifdef _OPENMP
+            tid = omp_get_thread_num();
+#endif
+            int ni = npts[i], ofs = vofs[i];
+            double* err = scratch + (size_t)tid * rowbuf;
+            double* Je = err + maxPoints * 2;
+            double* J_LR = Je + maxPoints * 2 * 6;
+            double* Ji = J_LR + maxPoints * 2 * 6;
+            double* Uloc = Uacc + (size_t)tid * nacc;
+            double* gsloc = Uloc + (size_t)ns * ns;
             double* om0 = lm.param + (i + 1) * 6;
             double* T0 = om0 + 3;
             double omR[3], tR[3], dr3dr1[9], dr3dr2[9], dt3dr2[9], dt3dt1[9], dt3dt2[9];
@@ -740,10 +762,10 @@ double orc_stereo_calibrate(int nviews, const int* npts, const double* obj, cons
                         if (k == 1) {
                             for (int a = 0; a < 6; a++) {
                                 for (int b = 0; b < 6; b++) {
-                                    ss.U[a * ns + b] += JLtJL[a * 6 + b];
+                                    Uloc[a * ns + b] += JLtJL[a * 6 + b];
                                     Wi[a * 6 + b] = JLtJe[a * 6 + b];
                                 }
-                                ss.gs[a] += JLte[a];
+                                gsloc[a] += JLte[a];
                             }
                         }
                         for (int a = 0; a < 6; a++) {
@@ -752,18 +774,26 @@ double orc_stereo_calibrate(int nviews, const int* npts, const double* obj, cons
                         }
                         if (recomputeIntrinsics) {
                             for (int a = 0; a < NI; a++) {
-                                for (int b = 0; b < NI; b++) ss.U[(so + a) * ns + so + b] += JitJi[a * NI + b];
-                                ss.gs[so + a] += Jite[a];
+                                for (int b = 0; b < NI; b++) Uloc[(so + a) * ns + so + b] += JitJi[a * NI + b];
+                                gsloc[so + a] += Jite[a];
                                 for (int b = 0; b < 6; b++) Wi[(so + a) * 6 + b] += JetJi[b * NI + a];
                                 if (k == 1)
-                                    for (int b = 0; b < 6; b++) ss.U[b * ns + so + a] += JLtJi[b * NI + a];
+                                    for (int b = 0; b < 6; b++) Uloc[b * ns + so + a] += JLtJi[b * NI + a];
                             }
                         }
                     }
                 }
                 double viewErr = 0;
                 for (int j = 0; j < 2 * ni; j++) viewErr += err[j] * err[j];
-                reprojErr += viewErr;
+                gsloc[ns] += viewErr;
+            }
+        }
+        for (int t = 0; t < nth; t++) {
+            const double* acc = Uacc + (size_t)t * nacc;
+            reprojErr += acc[nacc - 1];
+            if (calcJ && schur) {
+                for (int a = 0; a < ns * ns; a++) ss.U[a] += acc[a];
+                for (int a = 0; a < ns; a++) ss.gs[a] += acc[(size_t)ns * ns + a];
             }
         }
         if (wantErr) lm.errNorm = reprojErr;
@@ -804,7 +834,7 @@ double orc_stereo_calibrate(int nviews, const int* npts, const double* obj, cons
         stats->final_err = reprojErr;
     }
     if (schur) schur_free(&ss);
-    free(err), free(Je), free(J_LR), free(Ji);
+    free(scratch), free(Uacc), free(vofs);
     orc_lm_free(&lm);
     return sqrt(reprojErr / (pointsTotal * 2));
 }
