@@ -115,6 +115,14 @@ def main():
             except Exception as e:  # noqa: BLE001
                 print(f"[rank {rank}] in-stream RCCL unavailable ({e}); using torch.distributed", file=sys.stderr)
                 mode = "torch"
+            # the ranks must agree: one rank on the callback path while the others wait in ncclAllReduce hangs the job
+            ok = torch.tensor([1 if mode == "rccl" else 0], dtype=torch.int32,
+                              device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and mode == "rccl":
+                solver.close()
+                solver = pkg.Solver(obj, ms.img, device=local_rank)
+                mode = "torch"
         if mode == "torch":
             gloo = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else None
 

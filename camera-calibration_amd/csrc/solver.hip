@@ -86,6 +86,7 @@ struct ccalib_solver {
     unsigned long long* h_flag = nullptr;    // pinned
     unsigned* d_counter = nullptr;
     unsigned long long seq = 0;
+    double wait_limit_s = 120.;         // longest wait for one pass's sums (CCALIB_WAIT_LIMIT_S)
     double t_wait = 0, t_enqueue = 0;  // host seconds spent polling / inside backend calls before polling
     std::chrono::steady_clock::time_point t_enter;
     static constexpr int kRedCap = 4096;
@@ -207,6 +208,10 @@ int finish_reduction(ccalib_solver* s, int n) {
             if (q != hipSuccess && q != hipErrorNotReady)
                 return set_error(CCALIB_ERR_HIP, "stream failed while waiting for a reduction: %s", hipGetErrorString(q));
             if (q == hipSuccess && *flag != seq) return set_error(CCALIB_ERR_HIP, "reduction finished without publishing");
+            // nor must a peer that left a sharded run (its all-reduce never completes): bounded wait
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count() > s->wait_limit_s)
+                return set_error(CCALIB_ERR_HIP, "no reduction result after %.0f s (a rank of a sharded run may have stopped)",
+                                 s->wait_limit_s);
         }
         __builtin_ia32_pause();
     }
@@ -585,17 +590,19 @@ int ccalib_solver_create(ccalib_solver** out, int device, int ncams, int nviews,
     if (device < 0 || device >= ndev) return set_error(CCALIB_ERR_ARG, "device %d out of range (%d present)", device, ndev);
     HIP_TRY(hipSetDevice(device));
     ccalib_solver* s = new ccalib_solver();
+    // everything allocated so far is released if any step below fails
+    struct CreateGuard {
+        ccalib_solver* s;
+        ~CreateGuard() {
+            if (s) ccalib_solver_destroy(s);
+        }
+    } guard{s};
     s->device = device, s->ncams = ncams, s->nviews = nviews, s->shared_board = shared_board != 0;
     std::vector<int> off(nviews + 1, 0);
     for (int i = 0; i < nviews; i++) {
-        if (npts[i] < 4) {
-            delete s;
-            return set_error(CCALIB_ERR_ARG, "view %d has %d points (at least 4 needed)", i, npts[i]);
-        }
-        if (shared_board && npts[i] != npts[0]) {
-            delete s;
+        if (npts[i] < 4) return set_error(CCALIB_ERR_ARG, "view %d has %d points (at least 4 needed)", i, npts[i]);
+        if (shared_board && npts[i] != npts[0])
             return set_error(CCALIB_ERR_ARG, "shared_board needs the same point count in every view");
-        }
         off[i + 1] = off[i] + npts[i];
         s->maxnp = std::max(s->maxnp, npts[i]);
     }
@@ -629,6 +636,7 @@ int ccalib_solver_create(ccalib_solver** out, int device, int ncams, int nviews,
     if (const char* e = std::getenv("CCALIB_NO_FUSED")) s->use_fused = std::atoi(e) == 0;
     s->grid_err = std::min((nviews + 3) / 4, 2048);  // eight wavefronts per SIMD
     if (const char* e = std::getenv("CCALIB_NO_AHEAD")) s->speculate = std::atoi(e) == 0;
+    if (const char* e = std::getenv("CCALIB_WAIT_LIMIT_S")) s->wait_limit_s = std::max(1., std::atof(e));
     if (fused_geom(s->maxnp, s->shared_board, s->board_np).lds_bytes > 64 * 1024) s->use_fused = false;
     s->nblk64 = (nviews + 63) / 64;
     s->npad = (nviews + 63) / 64 * 64;
@@ -653,12 +661,14 @@ int ccalib_solver_create(ccalib_solver** out, int device, int ncams, int nviews,
         for (int b = 0; b < 2; b++) HIP_TRY(hipMalloc(&s->d_cmp[b], sizeof(double) * kCmpRows * s->npad));
     }
     HIP_TRY(hipMalloc(&s->d_red, sizeof(double) * ccalib_solver::kRedCap));
-    HIP_TRY(hipHostMalloc(&s->h_red, sizeof(double) * ccalib_solver::kRedCap));
-    HIP_TRY(hipHostMalloc(&s->h_flag, sizeof(unsigned long long)));
+    // coherent (uncached on the device side): the host reads these while the stream that writes them is still running
+    HIP_TRY(hipHostMalloc(&s->h_red, sizeof(double) * ccalib_solver::kRedCap, hipHostMallocCoherent));
+    HIP_TRY(hipHostMalloc(&s->h_flag, sizeof(unsigned long long), hipHostMallocCoherent));
     *s->h_flag = 0;
     HIP_TRY(hipMalloc(&s->d_counter, sizeof(unsigned)));
     HIP_TRY(hipMemset(s->d_counter, 0, sizeof(unsigned)));
     s->segs.nseg = 0;
+    guard.s = nullptr;
     *out = s;
     return CCALIB_OK;
 }
@@ -710,7 +720,8 @@ int ccalib_solver_set_start(ccalib_solver* s, const double* intr, const unsigned
         s->rational[c] = rat;
         for (int b = 0; b < 2; b++)
             if (m != s->ops[c] || !s->d_blk[c][b]) {
-                if (s->d_blk[c][b]) HIP_TRY(hipFree(s->d_blk[c][b]));
+                if (s->d_blk[c][b]) (void)hipFree(s->d_blk[c][b]);
+                s->d_blk[c][b] = nullptr;  // a failed allocation below must not leave a freed pointer behind
                 HIP_TRY(hipMalloc(&s->d_blk[c][b], sizeof(double) * (size_t)m->NBLK * s->npad));
             }
         s->ops[c] = m;
@@ -718,7 +729,8 @@ int ccalib_solver_set_start(ccalib_solver* s, const double* intr, const unsigned
     {
         size_t need = part_capacity(s);
         if (need > s->part_cap) {
-            if (s->d_part) HIP_TRY(hipFree(s->d_part));
+            if (s->d_part) (void)hipFree(s->d_part);
+            s->d_part = nullptr, s->part_cap = 0;
             HIP_TRY(hipMalloc(&s->d_part, sizeof(double) * need));
             s->part_cap = need;
         }
@@ -841,9 +853,18 @@ int ccalib_solver_init_poses(ccalib_solver* s, int cam, const double* K, const d
     HIP_TRY(hipMemcpyAsync(status.data(), s->d_status, sizeof(int) * s->nviews, hipMemcpyDeviceToHost, s->stream));
     if (rt_out) HIP_TRY(hipMemcpyAsync(rt_out, dst, sizeof(double) * 6 * s->nviews, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    for (int i = 0; i < s->nviews; i++)
-        if (status[i] != 0)
-            return set_error(CCALIB_ERR_UNSUPPORTED, "view %d: pose initialisation is built for planar calibration rigs only", i);
+    int first_bad = -1;
+    for (int i = 0; i < s->nviews && first_bad < 0; i++)
+        if (status[i] != 0) first_bad = i;
+    // in a sharded run the decision is taken together: a rank that left here alone would leave the others waiting
+    // in the next all-reduce
+    double nbad = first_bad >= 0 ? 1. : 0.;
+    int rc = allreduce_host(s, &nbad, 1);
+    if (rc) return rc;
+    if (first_bad >= 0)
+        return set_error(CCALIB_ERR_UNSUPPORTED, "view %d: pose initialisation is built for planar calibration rigs only", first_bad);
+    if (nbad > 0.)
+        return set_error(CCALIB_ERR_UNSUPPORTED, "pose initialisation failed on another rank (planar calibration rigs only)");
     s->poses_ready[cam] = true;
     s->pc_fresh = false;
     return CCALIB_OK;
@@ -862,11 +883,62 @@ int ccalib_solver_init_relative_pose(ccalib_solver* s, double* lr) {
     HIP_TRY(hipMemcpyAsync(rel.data(), d_rel, sizeof(double) * rel.size(), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     const int n = s->nviews;
-    for (int a = 0; a < 6; a++) {  // per-component median, as cvStereoCalibrateImpl seeds om_LR, T_LR
-        double* col = rel.data() + (size_t)a * s->npad;
-        std::nth_element(col, col + n / 2, col + n);
-        double hi = col[n / 2];
-        lr[a] = n % 2 ? hi : (*std::max_element(col, col + n / 2) + hi) * 0.5;
+    if (!s->comm && !s->cb) {
+        for (int a = 0; a < 6; a++) {  // per-component median, as cvStereoCalibrateImpl seeds om_LR, T_LR
+            double* col = rel.data() + (size_t)a * s->npad;
+            std::nth_element(col, col + n / 2, col + n);
+            double hi = col[n / 2];
+            lr[a] = n % 2 ? hi : (*std::max_element(col, col + n / 2) + hi) * 0.5;
+        }
+        return CCALIB_OK;
+    }
+    // Sharded run: the median is taken over the views of ALL ranks, exactly.  Doubles are mapped to 64-bit keys
+    // in the same order; for every component the key of the wanted order statistic is found by bisection on the
+    // key, each round asking all ranks how many of their values lie at or below the probe (one all-reduce of twelve
+    // counts per round, 64 rounds).  Every rank ends with the same bits a single solver over all views computes.
+    auto to_key = [](double v) {
+        unsigned long long b;
+        std::memcpy(&b, &v, 8);
+        return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+    };
+    auto from_key = [](unsigned long long k) {
+        unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+        double v;
+        std::memcpy(&v, &b, 8);
+        return v;
+    };
+    std::vector<std::vector<unsigned long long>> keys(6, std::vector<unsigned long long>(n));
+    for (int a = 0; a < 6; a++) {
+        for (int i = 0; i < n; i++) keys[a][i] = to_key(rel[(size_t)a * s->npad + i]);
+        std::sort(keys[a].begin(), keys[a].end());
+    }
+    double cnt = (double)n;
+    int rc = allreduce_host(s, &cnt, 1);
+    if (rc) return rc;
+    const long long N = std::llround(cnt);
+    // searches 0..5: order statistic N/2 of each component; 6..11: N/2 - 1 (used when N is even)
+    unsigned long long lo[12], hi[12];
+    long long want[12];
+    for (int j = 0; j < 12; j++) lo[j] = 0, hi[j] = ~0ull, want[j] = j < 6 ? N / 2 : std::max(0ll, N / 2 - 1);
+    for (int round = 0; round < 64; round++) {
+        double c[12];
+        unsigned long long mid[12];
+        for (int j = 0; j < 12; j++) {
+            mid[j] = lo[j] + (hi[j] - lo[j]) / 2;
+            const auto& k = keys[j % 6];
+            c[j] = (double)(std::upper_bound(k.begin(), k.end(), mid[j]) - k.begin());
+        }
+        if ((rc = allreduce_host(s, c, 12))) return rc;
+        for (int j = 0; j < 12; j++) {
+            if (std::llround(c[j]) >= want[j] + 1)
+                hi[j] = mid[j];
+            else
+                lo[j] = mid[j] + 1;
+        }
+    }
+    for (int a = 0; a < 6; a++) {
+        const double vhi = from_key(lo[a]), vlo = from_key(lo[6 + a]);
+        lr[a] = N % 2 ? vhi : (vlo + vhi) * 0.5;
     }
     return CCALIB_OK;
 }

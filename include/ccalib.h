@@ -103,7 +103,9 @@ int ccalib_calibrate_camera(int nviews, const int* npts, const float* obj_xyz, c
 /*
  * cv::stereoCalibrate (binocular_chessboard.cpp:152-162, binocular_circle.cpp:153-163).
  *   K1,K2 in/out 3x3; dist1,dist2 in/out 14 doubles each; R 3x3, T 3, E 3x3, F 3x3 out.
- *   init_rt (nviews x 6 camera-0 poses) and init_lr (6: om_LR|T_LR) are optional starts.
+ *   init_rt (nviews x 6 camera-0 poses) and init_lr (6: om_LR|T_LR) are an optional start: both or neither
+ *   (exactly one of them is CCALIB_ERR_ARG); with neither, the poses and the relative pose are initialised on the
+ *   device as OpenCV does.
  *   rt_out optional nviews x 6 refined camera-0 poses.
  *   rms = sqrt(sum err^2 / (2 * sum npts)).
  */
@@ -214,8 +216,11 @@ int ccalib_solver_set_start(ccalib_solver* s, const double* intr, const unsigned
  *                       undistorted points, pose from it, 6-parameter LM refinement.  Camera 0's poses
  *                       stay on the device as the starting poses (pass rt = NULL to set_start);
  *                       rt_out (optional) receives nviews x 6 (r|t).  Planar rigs only.
- *   init_relative_pose  stereo, after init_poses for both cameras: lr[6] = per-component median over
- *                       this solver's views of the relative pose (om | T) of camera 1 w.r.t. camera 0.
+ *   init_relative_pose  stereo, after init_poses for both cameras: lr[6] = per-component median of the relative
+ *                       pose (om | T) of camera 1 w.r.t. camera 0 over the views.  In a multi-GPU run (after
+ *                       use_rccl / use_callback; every rank must call it) the median is the exact one over the
+ *                       views of ALL ranks, found by bisection with all-reduced counts: every rank receives the
+ *                       bits a single solver over all views computes.
  */
 int ccalib_solver_init_intrinsics(ccalib_solver* s, int cam, int width, int height, double aspect,
                                   double* K);
@@ -240,7 +245,6 @@ int ccalib_solver_use_callback(ccalib_solver* s, ccalib_allreduce_fn fn, void* u
 /*
  * Runs the CvLevMarq state machine (damping, reduced solve, convergence on the host; passes on
  * the GPU) until done.  solve_method: 0 LU (CALIB_USE_LU), 1 eigen/SVD (OpenCV's default).
- * total_points is the GLOBAL point count (all ranks) used for the RMS; pass 0 for "this rank's".
  * May be called again to continue (bench.py runs a fixed number of iterations with eps = 0).
  */
 int ccalib_solver_run(ccalib_solver* s, int term_type, int max_iter, double eps, int solve_method,

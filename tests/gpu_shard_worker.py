@@ -19,6 +19,16 @@ def main():
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     pkg = ge.load_package()
+
+    def rccl_id():
+        ids = [None]
+        if rank == 0:
+            buf = C.create_string_buffer(128)
+            pkg.capi.check(pkg.capi.load().ccalib_rccl_unique_id(buf))
+            ids = [buf.raw]
+        dist.broadcast_object_list(ids, src=0)
+        return ids[0]
+
     synth = pkg.synth
     obj = synth.chessboard(9, 6, 25.0)
     per_rank, seed = 500, 123
@@ -32,13 +42,7 @@ def main():
     if mode == "callback":
         s.use_callback(lambda a: dist.all_reduce(torch.from_numpy(a)))
     else:
-        ids = [None]
-        if rank == 0:
-            buf = C.create_string_buffer(128)
-            pkg.capi.check(pkg.capi.load().ccalib_rccl_unique_id(buf))
-            ids = [buf.raw]
-        dist.broadcast_object_list(ids, src=0)
-        s.use_rccl(world, rank, ids[0])
+        s.use_rccl(world, rank, rccl_id())
     s.set_start(intr, mask, rt0)
     crit = (3, 30, 1e-8)
     st = s.run(criteria=crit)
@@ -64,6 +68,8 @@ def main():
     s = pkg.Solver(obj, ms.img, device=dev)
     if mode == "callback":
         s.use_callback(lambda a: dist.all_reduce(torch.from_numpy(a)))
+    else:
+        s.use_rccl(world, rank, rccl_id())
     Ksh = s.init_intrinsics((640, 480))
     rt_sh = s.init_poses(Ksh, None)
     s.close()
@@ -79,7 +85,8 @@ def main():
         assert np.abs(rt_sh - rt_one[:per_rank]).max() < 1e-6 * max(1.0, np.abs(rt_one).max())
         print("GPU_SHARDED_INIT_OK", mode)
 
-    # stereo, sharded: each rank owns half of the pairs; the relative-pose seed is rank 0's median, broadcast
+    # stereo, sharded: each rank owns half of the pairs; the relative-pose seed is the exact median over the pairs
+    # of all ranks (bisection with all-reduced counts), so every rank holds the single-solver seed bit for bit
     npairs = 120
     flags = (pkg.CALIB_FIX_ASPECT_RATIO | pkg.CALIB_ZERO_TANGENT_DIST | pkg.CALIB_SAME_FOCAL_LENGTH |
              pkg.CALIB_RATIONAL_MODEL | pkg.CALIB_FIX_K3 | pkg.CALIB_FIX_K4 | pkg.CALIB_FIX_K5)
@@ -94,27 +101,23 @@ def main():
         so = pkg.Solver(obj, img1, img2, device=dev if shard else 0)
         if shard and mode == "callback":
             so.use_callback(lambda a: dist.all_reduce(torch.from_numpy(a)))
+        elif shard:
+            so.use_rccl(world, rank, rccl_id())
         so.init_poses(K1, None, cam=0, want=False)
         so.init_poses(K1, None, cam=1, want=False)
         lr = so.init_relative_pose()
-        if shard:
-            box = [lr]
-            dist.broadcast_object_list(box, src=0)
-            lr = box[0]
         so.set_start(intr2, mask2, None, aspect=[1.0, 1.0], same_focal=True, lr=lr)
         sst = so.run(criteria=(3, 40, 1e-7))
         res = so.get()
         so.close()
         return sst, res, lr
     st_s, out_s, lr_s = stereo_run(sw.img1[lo:hi], sw.img2[lo:hi], True)
+    seeds = [None] * world
+    dist.all_gather_object(seeds, lr_s)
+    assert all(np.array_equal(g, seeds[0]) for g in seeds)            # every rank computed the same bits
     if rank == 0:
-        so = pkg.Solver(obj, sw.img1, sw.img2, device=0)
-        so.init_poses(K1, None, cam=0, want=False)
-        so.init_poses(K1, None, cam=1, want=False)
-        so.set_start(intr2, mask2, None, aspect=[1.0, 1.0], same_focal=True, lr=lr_s)   # same seed as the sharded run
-        st_1 = so.run(criteria=(3, 40, 1e-7))
-        ref_s = so.get()
-        so.close()
+        st_1, ref_s, lr_1 = stereo_run(sw.img1, sw.img2, False)        # one solver over all pairs, its own seed
+        assert np.array_equal(lr_s, lr_1), (lr_s, lr_1)               # sharded seed == single-solver seed, bit for bit
         assert abs(st_s["iters"] - st_1["iters"]) <= 1, (st_s, st_1)
         assert abs(out_s["err"] - ref_s["err"]) <= 1e-8 * ref_s["err"]
         assert np.allclose(out_s["intr"], ref_s["intr"], rtol=1e-6, atol=1e-10)

@@ -458,6 +458,41 @@ def test_two_ranks_shard_views_callback_allreduce():
     assert "GPU_SHARDED_STEREO_OK callback" in out.stdout         # stereoCalibrate sharded over pairs
 
 
+def test_two_ranks_rccl_allreduce_one_gpu_per_rank():
+    """The same worker with in-stream RCCL all-reduces over a two-rank communicator, one GPU per rank.  Runs wherever
+    two GPUs are visible (the launcher starts before anything here touches a GPU); skipped on a one-GPU box."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (one per rank): RCCL refuses two ranks on one device")
+    out = _run_shard_worker("rccl", 29623)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    for tag in ("GPU_SHARDED_OK rccl", "GPU_SHARDED_INIT_OK rccl", "GPU_SHARDED_STEREO_OK rccl"):
+        assert tag in out.stdout
+
+
+def test_bench_two_ranks_gloo_rehearsal():
+    """bench.py --gpus 2 end to end as the driver launches it (torch.distributed.run, one JSON line from rank 0),
+    rehearsed on whatever GPUs are present: with CCALIB_BENCH_BACKEND=gloo the ranks share GPUs and every sum goes
+    through the host callback."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", CCALIB_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29625", os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--steps", "4", "--warmup", "1", "--views", "3000", "--no-cpu"],
+                         env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 4 and r["scaling"] == "weak"
+    assert r["config"]["views_per_gpu"] == 3000 and r["config"]["allreduce"] == "torch"
+    assert 0.3 < r["rms_px"] < 0.6 and r["value"] > 0
+
+
 def test_rccl_allreduce_path(pkg, synth):
     """In-stream RCCL all-reduce: a one-rank communicator on this box (multi-rank needs one GPU per rank)."""
     import ctypes as C
