@@ -261,6 +261,12 @@ class Solver:
         capi.check(self._lib.ccalib_solver_get(self._h, _p(intr), _p(rt), _p(lr), C.byref(err)))
         return dict(intr=intr, rt=rt, lr=lr, err=err.value)
 
+    def counters(self):
+        """dict(ahead, used, dropped): iterations the GPU ran ahead of the host state machine (see ccalib.h)."""
+        c = (C.c_longlong * 3)()
+        capi.check(self._lib.ccalib_solver_counters(self._h, c))
+        return dict(ahead=c[0], used=c[1], dropped=c[2])
+
     def eval_error(self):
         e = C.c_double()
         capi.check(self._lib.ccalib_solver_eval_error(self._h, C.byref(e)))

@@ -19,7 +19,7 @@ SYMBOLS = [
     "ccalib_init_camera_matrix_2d", "ccalib_write_mono_yaml", "ccalib_write_stereo_yaml",
     "ccalib_solver_create", "ccalib_solver_destroy", "ccalib_solver_set_start",
     "ccalib_rccl_unique_id", "ccalib_solver_use_rccl", "ccalib_solver_use_callback",
-    "ccalib_solver_run", "ccalib_solver_get", "ccalib_solver_num_shared",
+    "ccalib_solver_run", "ccalib_solver_get", "ccalib_solver_counters", "ccalib_solver_num_shared",
     "ccalib_solver_eval_error", "ccalib_solver_eval_jacobian", "ccalib_solver_fetch_blocks",
     "ccalib_solver_reduce", "ccalib_solver_time_kernels", "ccalib_lm_run",
     "ccalib_solver_init_intrinsics", "ccalib_solver_init_poses", "ccalib_solver_init_relative_pose",

@@ -29,6 +29,8 @@
 #include <cstdlib>
 
 #include "device_math.hpp"
+#include "lm_step.hpp"
+#include "lm_step_body.hpp"
 
 namespace ccalib {
 
@@ -391,8 +393,13 @@ __global__ __launch_bounds__(64) void k_pose_const(const double* pose, int nview
 template <class M, bool SHARED, bool MULTI, int TPB>
 __global__ __launch_bounds__(kBlock * TPB, TPB == 1 ? 3 : 1) void k_jac_fused(PassArgs a, CamParams cp, const int* __restrict__ off,
                                                          const double* __restrict__ pc, double* __restrict__ blk,
-                                                         double* __restrict__ part, int RS, int CH) {
+                                                         double* __restrict__ part, int RS, int CH,
+                                                         const LmCtrl* __restrict__ ctrl, int cam) {
     constexpr int NC = M::NC, NB = M::NBLK, NU = M::NU, NR = M::NRED_U;
+    if (ctrl) {  // an iteration run ahead of the host: camera parameters and the go word come from device memory
+        if (!ctrl->go) return;
+        cp = ctrl->cp[cam];
+    }
     constexpr int CPOSE = NC, CRES = NC + 6, NCOL = NC + 7;
     static_assert(NCOL <= 16, "column set does not fit one 16x16 tile");
     static_assert(kWaves == kTileViews, "one wavefront per view of a tile");
@@ -678,8 +685,10 @@ __global__ __launch_bounds__(kBlock * TPB, TPB == 1 ? 3 : 1) void k_jac_fused(Pa
 // One lane per view, one wavefront per workgroup.  Output per workgroup: the upper triangle of
 // sum W V'^-1 W^T over its 64 views (NC(NC+1)/2 values) followed by sum W V'^-1 ge (NC values).
 template <int NC>
-__global__ __launch_bounds__(64) void k_schur(const double* blk, int npad, int nviews, double lambda, double* part) {
+__global__ __launch_bounds__(64) void k_schur(const double* blk, int npad, int nviews, double lambda, double* part,
+                                              const LmCtrl* __restrict__ ctrl) {
     constexpr int NS = NC * (NC + 1) / 2 + NC, NB = 27 + 6 * NC;
+    if (ctrl && !ctrl->go) return;
     int v = blockIdx.x * 64 + threadIdx.x;
     bool live = v < nviews;
     int vv = live ? v : nviews - 1;
@@ -723,8 +732,14 @@ __global__ __launch_bounds__(64) void k_schur(const double* blk, int npad, int n
 // With pc != null the trial pose is also written in the form the fused Jacobian kernel reads.
 template <int NC>
 __global__ __launch_bounds__(64) void k_backsub(const double* blk, int npad, int nviews, double lambda, DeltaC dc,
-                                                const double* pose_prev, double* pose_cur, double* part, double* pc) {
+                                                const double* pose_prev, double* pose_cur, double* part, double* pc,
+                                                const LmCtrl* __restrict__ ctrl) {
     constexpr int NB = 27 + 6 * NC;
+    if (ctrl) {  // an iteration run ahead of the host: the step comes from device memory
+        if (!ctrl->go) return;
+#pragma unroll
+        for (int i = 0; i < NC; i++) dc.v[i] = ctrl->dc[i];
+    }
     int v = blockIdx.x * 64 + threadIdx.x;
     bool live = v < nviews;
     int vv = live ? v : nviews - 1;
@@ -773,8 +788,11 @@ __global__ __launch_bounds__(64) void k_backsub(const double* blk, int npad, int
 // `out` may be host memory the device can write; the last workgroup to finish then stores `seq` to
 // *flag (also host memory), which a polling host thread takes as "all sums have landed".
 __global__ __launch_bounds__(kBlock) void k_colsum(ColsumArgs a, double* out, unsigned* counter,
-                                                   volatile unsigned long long* flag, unsigned long long seq) {
+                                                   volatile unsigned long long* flag, unsigned long long seq,
+                                                   const LmCtrl* __restrict__ ctrl, LmStepArgs st, int has_step) {
     __shared__ double sm[kBlock];
+    __shared__ int is_last;
+    if (ctrl && !ctrl->go) return;
     int k = blockIdx.x, sidx = 0;
     while (sidx + 1 < a.nseg && k >= a.seg[sidx].n) k -= a.seg[sidx].n, sidx++;
     const ColsumSeg sg = a.seg[sidx];
@@ -796,14 +814,25 @@ __global__ __launch_bounds__(kBlock) void k_colsum(ColsumArgs a, double* out, un
     }
     if (threadIdx.x == 0) {
         out[sg.out_ofs + k] = sm[0];
-        if (flag) {
+        is_last = 0;
+        if (flag || has_step) {
             __threadfence_system();
             if (atomicAdd(counter, 1u) == gridDim.x - 1) {
                 *counter = 0;
                 __threadfence_system();
-                *flag = seq;
+                if (has_step)
+                    is_last = 1;
+                else
+                    *flag = seq;
             }
         }
+    }
+    if (has_step) {
+        // The workgroup that finishes last holds every sum of the pass: its first wavefront publishes them and
+        // predicts the host's next step (lm_step_body.hpp) without another kernel boundary in between.
+        __shared__ LmStepLds w;
+        __syncthreads();
+        if (is_last && threadIdx.x < 64) lm_step_body(st, w, threadIdx.x);
     }
 }
 
@@ -849,7 +878,7 @@ static void launch_jac_view(const PassArgs& a, const CamParams& cp, int grid, do
 }
 template <class M>
 static void launch_jac_fused(const PassArgs& a, const CamParams& cp, const double* pc, int grid, double* blk, double* part,
-                             hipStream_t st) {
+                             hipStream_t st, const LmCtrl* ctrl, int cam) {
     constexpr bool const_cols = M::index_of(I_CX) >= 0 && M::index_of(I_CY) == M::index_of(I_CX) + 1;
     FusedGeom g = fused_geom(a.maxnp, a.shared_board != 0, a.board_np, const_cols);
     // `grid` counts tiles in flight.  Three one-tile workgroups per CU if their LDS allows it; otherwise, if it
@@ -861,11 +890,11 @@ static void launch_jac_fused(const PassArgs& a, const CamParams& cp, const doubl
         auto f3 = k_jac_fused<M, decltype(shared)::value, decltype(multi)::value, 3>;
         if (three && hipFuncSetAttribute(reinterpret_cast<const void*>(f3), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)g3.lds_bytes) == hipSuccess) {
-            f3<<<dim3(grid / 3), dim3(3 * kBlock), g3.lds_bytes, st>>>(a, cp, a.off, pc, blk, part, g.RS, g.CH);
+            f3<<<dim3(grid / 3), dim3(3 * kBlock), g3.lds_bytes, st>>>(a, cp, a.off, pc, blk, part, g.RS, g.CH, ctrl, cam);
         } else {
             if (three) (void)hipGetLastError();  // the refused attribute must not surface as a launch error later
             k_jac_fused<M, decltype(shared)::value, decltype(multi)::value, 1>
-                <<<dim3(grid), dim3(kBlock), g.lds_bytes, st>>>(a, cp, a.off, pc, blk, part, g.RS, g.CH);
+                <<<dim3(grid), dim3(kBlock), g.lds_bytes, st>>>(a, cp, a.off, pc, blk, part, g.RS, g.CH, ctrl, cam);
         }
     };
     using T = std::true_type;
@@ -877,14 +906,16 @@ static void launch_jac_fused(const PassArgs& a, const CamParams& cp, const doubl
         multi ? go(F{}, T{}) : go(F{}, F{});
 }
 template <int NC>
-static void launch_schur(const double* blk, int npad, int nviews, double lambda, double* part, hipStream_t st) {
-    hipLaunchKernelGGL(k_schur<NC>, dim3((nviews + 63) / 64), dim3(64), 0, st, blk, npad, nviews, lambda, part);
+static void launch_schur(const double* blk, int npad, int nviews, double lambda, double* part, hipStream_t st,
+                         const LmCtrl* ctrl) {
+    hipLaunchKernelGGL(k_schur<NC>, dim3((nviews + 63) / 64), dim3(64), 0, st, blk, npad, nviews, lambda, part, ctrl);
 }
 template <int NC>
 static void launch_backsub(const double* blk, int npad, int nviews, double lambda, const DeltaC& dc,
-                           const double* pose_prev, double* pose_cur, double* part, double* pc, hipStream_t st) {
+                           const double* pose_prev, double* pose_cur, double* part, double* pc, hipStream_t st,
+                           const LmCtrl* ctrl) {
     hipLaunchKernelGGL(k_backsub<NC>, dim3((nviews + 63) / 64), dim3(64), 0, st, blk, npad, nviews, lambda, dc,
-                       pose_prev, pose_cur, part, pc);
+                       pose_prev, pose_cur, part, pc, ctrl);
 }
 
 template <class M>
@@ -948,10 +979,13 @@ void launch_reproj(const PassArgs& a, const CamParams& cp, bool rational, int gr
 }
 
 void launch_colsum(const ColsumArgs& a, double* out, unsigned* counter, unsigned long long* flag, unsigned long long seq,
-                   hipStream_t st) {
+                   hipStream_t st, const LmCtrl* ctrl, const LmStepArgs* step) {
     int total = 0;
     for (int i = 0; i < a.nseg; i++) total += a.seg[i].n;
-    if (total > 0) hipLaunchKernelGGL(k_colsum, dim3(total), dim3(kBlock), 0, st, a, out, counter, flag, seq);
+    static const LmStepArgs none = {};
+    if (total > 0)
+        hipLaunchKernelGGL(k_colsum, dim3(total), dim3(kBlock), 0, st, a, out, counter, flag, seq, ctrl, step ? *step : none,
+                           step ? 1 : 0);
 }
 
 void launch_publish(const double* src, int n, double* dst, unsigned long long* flag, unsigned long long seq, hipStream_t st) {

@@ -6,6 +6,9 @@
 
 namespace ccalib {
 
+struct LmCtrl;      // lm_step.hpp: control block of an iteration run ahead of the host (null = by-value arguments)
+struct LmStepArgs;  // lm_step.hpp
+
 struct PassArgs {
     const float2* img;   // view-major image points of one camera
     const float* obj;    // object points: 3*total floats, or 3*board_np when shared_board
@@ -54,13 +57,13 @@ struct ModelOps {
     int NC, NRED_U, NBLK;
     void (*jac_shared)(const PassArgs&, const CamParams&, int grid, double* part, hipStream_t);
     void (*jac_view)(const PassArgs&, const CamParams&, int grid, double* blk, int npad, hipStream_t);
-    void (*schur)(const double* blk, int npad, int nviews, double lambda, double* part, hipStream_t);
+    void (*schur)(const double* blk, int npad, int nviews, double lambda, double* part, hipStream_t, const LmCtrl* ctrl);
     void (*backsub)(const double* blk, int npad, int nviews, double lambda, const DeltaC&, const double* pose_prev,
-                    double* pose_cur, double* part, double* pc, hipStream_t);
+                    double* pose_cur, double* part, double* pc, hipStream_t, const LmCtrl* ctrl);
     // whole Jacobian pass in one kernel (shared block partials: 4 * grid rows of NRED_U); null when the
     // column set does not fit the 16-wide matrix tile
     void (*jac_fused)(const PassArgs&, const CamParams&, const double* pc, int grid, double* blk, double* part,
-                      hipStream_t);
+                      hipStream_t, const LmCtrl* ctrl, int cam);
     int col(int i) const {  // i-th produced column -> intrinsic index
         int seen = 0;
         for (int q = 0; q < I_NMODEL; q++)
@@ -91,8 +94,10 @@ struct ColsumArgs {
     ColsumSeg seg[kMaxColsumSegs];
     int nseg;
 };
+// With `step`, the workgroup that finishes last also runs the LM step prediction on the sums (which must then go
+// to device memory: step->red == out) and publishes through step->hred / step->flag instead of flag / seq.
 void launch_colsum(const ColsumArgs&, double* out, unsigned* counter, unsigned long long* flag, unsigned long long seq,
-                   hipStream_t);
+                   hipStream_t, const LmCtrl* ctrl = nullptr, const LmStepArgs* step = nullptr);
 void launch_publish(const double* src, int n, double* dst, unsigned long long* flag, unsigned long long seq, hipStream_t);
 int pass_block_size();
 // dynamic LDS one workgroup of the per-point kernels needs

@@ -18,6 +18,7 @@
 
 #include "ccalib.h"
 #include "host_util.hpp"
+#include "reduced_solve.hpp"
 
 namespace ccalib {
 
@@ -104,37 +105,8 @@ void eig_sym(std::vector<double> A, int n, std::vector<double>& w, std::vector<d
 // |w| <= 2 eps sum|w| as SVD back-substitution does.
 void solve_sym_svd(const std::vector<double>& A, std::vector<double>& b, int n) {
     if (n <= 64) {
-        double L[64 * 64], y[64], trace = 0;
-        for (int i = 0; i < n; i++) trace += std::fabs(A[i * n + i]);
-        const double cut = 1e4 * 2 * DBL_EPSILON * trace;
-        bool ok = true;
-        for (int i = 0; i < n && ok; i++) {
-            for (int j = 0; j <= i; j++) {
-                double sum = A[i * n + j];
-                for (int k = 0; k < j; k++) sum -= L[i * n + k] * L[j * n + k];
-                if (i == j) {
-                    if (!(sum > 1e-10 * A[i * n + i]) || !(sum > cut)) {
-                        ok = false;
-                        break;
-                    }
-                    L[i * n + i] = std::sqrt(sum);
-                } else
-                    L[i * n + j] = sum / L[j * n + j];
-            }
-        }
-        if (ok) {
-            for (int i = 0; i < n; i++) {
-                double sum = b[i];
-                for (int k = 0; k < i; k++) sum -= L[i * n + k] * y[k];
-                y[i] = sum / L[i * n + i];
-            }
-            for (int i = n - 1; i >= 0; i--) {
-                double sum = y[i];
-                for (int k = i + 1; k < n; k++) sum -= L[k * n + i] * b[k];
-                b[i] = sum / L[i * n + i];
-            }
-            return;
-        }
+        double L[64 * 64], y[64];
+        if (chol_solve_checked(A.data(), b.data(), n, L, y)) return;
     }
     std::vector<double> w, V, x(n, 0.);
     eig_sym(A, n, w, V);

@@ -24,6 +24,7 @@
 #include "host_util.hpp"
 #include "init_kernels.hpp"
 #include "kernels.hpp"
+#include "lm_step.hpp"
 #include "stereo_kernels.hpp"
 
 using namespace ccalib;
@@ -42,6 +43,12 @@ using namespace ccalib;
             return set_error(CCALIB_ERR_HIP, "%s failed: %s (%s:%d)", #expr, ncclGetErrorString(e_), \
                              __FILE__, __LINE__);                                                   \
     } while (0)
+
+// A pass whose sums are on their way to the host: which slot, and the value its flag will take.
+struct Pending {
+    int slot = 0;
+    unsigned long long seq = 0;
+};
 
 struct ccalib_solver {
     int device = 0, ncams = 1, nviews = 0, total = 0, maxnp = 0;
@@ -78,12 +85,15 @@ struct ccalib_solver {
     bool pc3_fresh = false;  // d_pc3 matches d_pose3
     // Partial results of the kernels of one pass: a bump-allocated arena, reduced by ONE column-sum
     // launch per pass whose output goes straight to pinned host memory; the host polls a flag there.
-    double* d_part = nullptr;
+    // Arena, reduction buffers and flag exist twice ("slots", used in turn): with an iteration run ahead the next
+    // pass is enqueued before the host has read the sums of the one before.
+    double* d_part[2] = {nullptr, nullptr};
     size_t part_cap = 0, part_used = 0;
     ColsumArgs segs;
-    double* d_red = nullptr;
-    double* h_red = nullptr;                 // pinned, device-writable
-    unsigned long long* h_flag = nullptr;    // pinned
+    int slot = 0;                                              // slot the next pass takes
+    double* d_red[2] = {nullptr, nullptr};
+    double* h_red[2] = {nullptr, nullptr};                     // pinned, device-writable
+    unsigned long long* h_flag[2] = {nullptr, nullptr};        // pinned
     unsigned* d_counter = nullptr;
     unsigned long long seq = 0;
     double wait_limit_s = 120.;         // longest wait for one pass's sums (CCALIB_WAIT_LIMIT_S)
@@ -121,6 +131,30 @@ struct ccalib_solver {
     // run settles into (e.g. every first trial at 1e-3 rejected, every retry at 1e-2 accepted).
     bool level_accepted[33];
     int last_level = 0;
+
+    // One iteration run ahead of the host (lm_step.hpp): the kernels of the next trial step are enqueued before the
+    // host has seen the sums of the current one and take their parameters from a control block the device writes.
+    bool chain_enabled = true;       // CCALIB_NO_CHAIN=1 turns it off
+    LmCtrl* d_ctrl = nullptr;        // [2], indexed by the slot of the iteration that reads it
+    LmMaps* d_maps = nullptr;
+    LmMaps h_maps;
+    std::vector<int> Uidx, gidx;     // shared block / gradient entry -> index among a Jacobian pass's sums
+    int err_idx[2] = {0, 0};
+    struct Chain {
+        bool inflight = false;       // enqueued and not yet claimed by the driver's next step
+        bool predicts = false;       // its k_lm_step predicts the iteration after it
+        double lambda = 0, lambda_next = 0;
+        int blk_base = 0;            // block buffer it steps from (its Jacobian goes to the other one)
+        double *pose_base = nullptr, *pose_trial = nullptr;
+        Pending pend;
+    } chain;
+    bool pred_go = false;            // what the last Jacobian pass's k_lm_step predicted for the next step
+    double pred_delta[kMaxShared], pred_shared[kMaxShared];
+    int run_solve_method = 1, run_max_iter = 0, commits = 0;
+    bool run_first_jac = false;
+    double drv_err = 0, committed_err = 0;  // residual sums as the driver holds them: latest trial / committed point
+    long long n_ahead = 0, n_ahead_used = 0, n_ahead_dropped = 0;
+    int slot_after() const { return slot ^ 1; }
 
     // multi-GPU
     ncclComm_t comm = nullptr;
@@ -165,11 +199,13 @@ PassArgs pass_args(const ccalib_solver* s, int cam, const double* pose) {
     return a;
 }
 
-// Arena for the partial results of the current pass.
+// Arena for the partial results of a pass.  There are two of everything a pass publishes through -- arena,
+// device and pinned reduction buffers, flag -- used in turn ("slots"), because with an iteration run ahead the
+// next pass is enqueued while the host has not yet read the sums of the one before.
 double* part_take(ccalib_solver* s, size_t n) {
     n = (n + 31) / 32 * 32;
     if (s->part_used + n > s->part_cap) return nullptr;
-    double* p = s->d_part + s->part_used;
+    double* p = s->d_part[s->slot] + s->part_used;
     s->part_used += n;
     return p;
 }
@@ -183,31 +219,50 @@ int queue_colsum(ccalib_solver* s, const double* part, int nrows, int n, int out
     return CCALIB_OK;
 }
 
-// Reduces everything queued in this pass into n sums, over ranks too (if any), and waits for them
-// in h_red.  Single rank and callback runs: the column-sum kernel writes pinned host memory directly
-// and raises a flag the host polls (no copy, no interrupt).  RCCL runs: sums land in d_red, are
-// all-reduced in-stream and then published the same way.
-int finish_reduction(ccalib_solver* s, int n) {
+// Reduces everything queued in this pass into n sums, over ranks too (if any), and sends them to the pinned
+// buffer of the current slot.  Plain passes: the column-sum kernel writes pinned host memory directly and raises
+// the flag (RCCL runs: sums land in device memory, are all-reduced in-stream and then published).  Jacobian
+// passes of a run that may run ahead (`step` given): the sums stay in device memory, and k_lm_step publishes them
+// together with its prediction of the next step.  `ctrl`: control block of a run-ahead iteration (its kernels
+// return at once when the iteration was called off), else null.
+int submit_reduction(ccalib_solver* s, int n, const LmCtrl* ctrl, LmStepArgs* step, Pending* out) {
+    const int q = s->slot;
     const unsigned long long seq = ++s->seq;
-    if (s->comm) {
-        launch_colsum(s->segs, s->d_red, s->d_counter, nullptr, 0, s->stream);
-        NCCL_TRY(ncclAllReduce(s->d_red, s->d_red, n, ncclDouble, ncclSum, s->comm, s->stream));
-        launch_publish(s->d_red, n, s->h_red, s->h_flag, seq, s->stream);
+    if (step) {
+        step->red = s->d_red[q], step->n = n, step->hred = s->h_red[q], step->flag = s->h_flag[q], step->seq = seq;
+        step->cin = ctrl;
+        if (s->comm) {  // the sums pass through the all-reduce first: the step runs as a kernel of its own after it
+            launch_colsum(s->segs, s->d_red[q], s->d_counter, nullptr, 0, s->stream, ctrl);
+            NCCL_TRY(ncclAllReduce(s->d_red[q], s->d_red[q], n, ncclDouble, ncclSum, s->comm, s->stream));
+            launch_lm_step(*step, s->stream);
+        } else  // single GPU: the last workgroup of the column-sum kernel runs it
+            launch_colsum(s->segs, s->d_red[q], s->d_counter, nullptr, 0, s->stream, ctrl, step);
+    } else if (s->comm) {
+        launch_colsum(s->segs, s->d_red[q], s->d_counter, nullptr, 0, s->stream, ctrl);
+        NCCL_TRY(ncclAllReduce(s->d_red[q], s->d_red[q], n, ncclDouble, ncclSum, s->comm, s->stream));
+        launch_publish(s->d_red[q], n, s->h_red[q], s->h_flag[q], seq, s->stream);
     } else {
-        launch_colsum(s->segs, s->h_red, s->d_counter, s->h_flag, seq, s->stream);
+        launch_colsum(s->segs, s->h_red[q], s->d_counter, s->h_flag[q], seq, s->stream, ctrl);
     }
     s->segs.nseg = 0;
     s->part_used = 0;
+    s->slot ^= 1;
     HIP_TRY(hipGetLastError());
+    out->slot = q, out->seq = seq;
+    return CCALIB_OK;
+}
+
+// Waits for the sums of a submitted pass; they are then in s->h_red[p.slot].
+int wait_reduction(ccalib_solver* s, const Pending& p, int n) {
     auto tw0 = std::chrono::steady_clock::now();
     s->t_enqueue += std::chrono::duration<double>(tw0 - s->t_enter).count();
-    volatile unsigned long long* flag = s->h_flag;
-    for (unsigned spins = 0; *flag != seq; spins++) {
+    volatile unsigned long long* flag = s->h_flag[p.slot];
+    for (unsigned spins = 0; *flag != p.seq; spins++) {
         if ((spins & 0xffff) == 0xffff) {  // a failed launch or a fault must not leave the host spinning
             hipError_t q = hipStreamQuery(s->stream);
             if (q != hipSuccess && q != hipErrorNotReady)
                 return set_error(CCALIB_ERR_HIP, "stream failed while waiting for a reduction: %s", hipGetErrorString(q));
-            if (q == hipSuccess && *flag != seq) return set_error(CCALIB_ERR_HIP, "reduction finished without publishing");
+            if (q == hipSuccess && *flag != p.seq) return set_error(CCALIB_ERR_HIP, "reduction finished without publishing");
             // nor must a peer that left a sharded run (its all-reduce never completes): bounded wait
             if (std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count() > s->wait_limit_s)
                 return set_error(CCALIB_ERR_HIP, "no reduction result after %.0f s (a rank of a sharded run may have stopped)",
@@ -217,10 +272,21 @@ int finish_reduction(ccalib_solver* s, int n) {
     }
     std::atomic_thread_fence(std::memory_order_acquire);
     s->t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count();
+    s->t_enter = std::chrono::steady_clock::now();
     if (s->cb) {
-        int rc = s->cb(s->cb_user, s->h_red, n);
+        int rc = s->cb(s->cb_user, s->h_red[p.slot], n);
         if (rc) return set_error(CCALIB_ERR_HIP, "all-reduce callback failed (%d)", rc);
     }
+    return CCALIB_OK;
+}
+
+// A plain pass: submit, wait; returns the pinned buffer holding the sums.
+int finish_reduction(ccalib_solver* s, int n, const double** red) {
+    Pending p;
+    int rc = submit_reduction(s, n, nullptr, nullptr, &p);
+    if (rc) return rc;
+    if ((rc = wait_reduction(s, p, n))) return rc;
+    *red = s->h_red[p.slot];
     return CCALIB_OK;
 }
 
@@ -236,11 +302,9 @@ size_t part_capacity(const ccalib_solver* s) {
     return n;
 }
 
-const double* cam_pose(const ccalib_solver* s, int cam) { return cam == 0 ? s->d_pose_cur : s->d_pose3; }
-
-// Residual pass of camera c at the current poses: partial sums (s->grid_err of them) into `part`.
+// Residual pass of camera c at the trial poses: partial sums (s->grid_err of them) into `part`.
 void enqueue_err(ccalib_solver* s, int c, const CamParams& cp, double* part) {
-    PassArgs a = pass_args(s, c, cam_pose(s, c));
+    PassArgs a = pass_args(s, c, c == 0 ? s->d_pose_cur : s->d_pose3);
     double* pc = c == 0 ? s->d_pc : s->d_pc3;
     bool& fresh = c == 0 ? s->pc_fresh : s->pc3_fresh;
     if (!fresh) launch_pose_const(a.pose, s->nviews, pc, s->stream);
@@ -270,68 +334,80 @@ void store_shared(ccalib_solver* s, const double* shared) {
 }
 
 // Stereo: camera-1 poses (and, for Jacobian passes, the composition derivatives, into buffer `buf`)
-// for the current camera-0 poses and relative pose.
-int stereo_compose(ccalib_solver* s, bool with_jac, int buf) {
+// for the camera-0 poses `pose1` and the current relative pose.
+int stereo_compose(ccalib_solver* s, bool with_jac, int buf, const double* pose1) {
     if (s->ncams != 2) return CCALIB_OK;
     StereoLR lr;
     for (int i = 0; i < 6; i++) lr.v[i] = s->lr[i];
     const bool want_pc3 = !with_jac || (s->ops[1]->jac_fused && s->use_fused);  // the residual kernel reads records too
-    launch_compose(s->d_pose_cur, lr, s->nviews, s->npad, s->d_pose3, with_jac ? s->d_cmp[buf] : nullptr,
+    launch_compose(pose1, lr, s->nviews, s->npad, s->d_pose3, with_jac ? s->d_cmp[buf] : nullptr,
                    want_pc3 ? s->d_pc3 : nullptr, s->stream);
     s->pc3_fresh = want_pc3;
     return CCALIB_OK;
 }
 
-// ---- the four backend operations --------------------------------------------------------------
+// ---- the backend operations ---------------------------------------------------------------------
 
-// Launches the Schur-sum kernels of buffer `buf` for `lambda` and appends their column sums to d_red
+// Launches the Schur-sum kernels of buffer `buf` for `lambda` and appends their column sums to the reduction
 // at `ofs`.  Layout appended: upper triangle (kc(kc+1)/2) then right-hand side (kc), kc = kernel columns.
-int enqueue_schur(ccalib_solver* s, int buf, double lambda, int ofs) {
+int enqueue_schur(ccalib_solver* s, int buf, double lambda, int ofs, const LmCtrl* ctrl) {
     int kc = s->kcols(), nsum = kc * (kc + 1) / 2 + kc;
     PART_TAKE(part, s, (size_t)s->nblk64 * nsum);
     if (s->ncams == 1)
-        s->ops[0]->schur(s->d_blk[0][buf], s->npad, s->nviews, lambda, part, s->stream);
+        s->ops[0]->schur(s->d_blk[0][buf], s->npad, s->nviews, lambda, part, s->stream, ctrl);
     else if (!launch_stereo_schur(s->ops[0]->NC, s->d_blk[0][buf], s->d_blk[1][buf], s->d_cmp[buf], s->lr_jac[buf],
                                   s->npad, s->nviews, lambda, part, s->stream))
         return set_error(CCALIB_ERR_UNSUPPORTED, "stereo column count %d is not built in", s->ops[0]->NC);
     return queue_colsum(s, part, s->nblk64, nsum, ofs);
 }
 
-// Where the sums of one Jacobian pass sit in d_red / h_red.
+// Where the sums of one Jacobian pass sit in the reduction buffer, relative to the pass's base offset.
 struct JacLayout {
     int cam_ofs[2] = {0, 0};
     int lr_ofs = 0, schur_ofs = 0, nsum = 0, end = 0;
 };
+JacLayout jac_layout(const ccalib_solver* s) {
+    JacLayout L;
+    int ofs = 0;
+    for (int c = 0; c < s->ncams; c++) L.cam_ofs[c] = ofs, ofs += s->ops[c]->NRED_U;
+    L.lr_ofs = ofs;
+    if (s->ncams == 2) ofs += 27 + 6 * s->ops[1]->NC;
+    L.schur_ofs = ofs;
+    const int kc = s->kcols();
+    L.nsum = kc * (kc + 1) / 2 + kc;
+    L.end = ofs + L.nsum;
+    return L;
+}
 
-// Enqueues a whole Jacobian pass at the solver's current parameters and trial poses into buffer
-// `buf`, with the Schur sums for `lambda_hint`; the reduced sums land in d_red from `ofs` on.
-int enqueue_jac(ccalib_solver* s, int buf, double lambda_hint, int ofs, JacLayout& L) {
-    int rc = stereo_compose(s, true, buf);
+// Enqueues a whole Jacobian pass into block buffer `buf`, with the Schur sums for `lambda_hint`; the reduced sums
+// land in the reduction buffer from `ofs` on, laid out as jac_layout() says.  The pass evaluates camera 0 at the
+// poses `pose` (records in d_pc must match them).  By-value parameters (the solver's current intrinsics and
+// relative pose) are used unless `ctrl` names the control block of a run-ahead iteration.
+int enqueue_jac(ccalib_solver* s, int buf, double lambda_hint, int ofs, const double* pose, const LmCtrl* ctrl) {
+    int rc = stereo_compose(s, true, buf, pose);
     if (rc) return rc;
+    const JacLayout L = jac_layout(s);
     for (int i = 0; i < 6; i++) s->lr_jac[buf].v[i] = s->lr[i];
     for (int c = 0; c < s->ncams; c++) {
         const ModelOps* m = s->ops[c];
         CamParams cp = cam_params(s->intr[c], s->aspect[c]);
-        PassArgs a = pass_args(s, c, cam_pose(s, c));
+        PassArgs a = pass_args(s, c, c == 0 ? pose : s->d_pose3);
         if (m->jac_fused && s->use_fused) {
             int rows = s->grid_fused;  // one row of partial sums per tile slot
             PART_TAKE(part, s, (size_t)rows * m->NRED_U);
             double* pc = c == 0 ? s->d_pc : s->d_pc3;
             bool& fresh = c == 0 ? s->pc_fresh : s->pc3_fresh;
-            if (!fresh) launch_pose_const(a.pose, s->nviews, pc, s->stream);
+            if (!fresh && !ctrl) launch_pose_const(a.pose, s->nviews, pc, s->stream);
             fresh = true;
-            m->jac_fused(a, cp, pc, s->grid_fused, s->d_blk[c][buf], part, s->stream);
-            if ((rc = queue_colsum(s, part, rows, m->NRED_U, ofs))) return rc;
+            m->jac_fused(a, cp, pc, s->grid_fused, s->d_blk[c][buf], part, s->stream, ctrl, c);
+            if ((rc = queue_colsum(s, part, rows, m->NRED_U, ofs + L.cam_ofs[c]))) return rc;
         } else {
             PART_TAKE(part, s, (size_t)s->grid_red * m->NRED_U);
             m->jac_shared(a, cp, s->grid_red, part, s->stream);
-            if ((rc = queue_colsum(s, part, s->grid_red, m->NRED_U, ofs))) return rc;
+            if ((rc = queue_colsum(s, part, s->grid_red, m->NRED_U, ofs + L.cam_ofs[c]))) return rc;
             m->jac_view(a, cp, s->grid_view, s->d_blk[c][buf], s->npad, s->stream);
         }
-        L.cam_ofs[c] = ofs;
-        ofs += m->NRED_U;
     }
-    L.lr_ofs = ofs;
     if (s->ncams == 2) {
         // shared-block pieces that involve the relative pose: B^T V3 B (21), B^T ge3 (6), W3 B (NC1 x 6)
         int n = 27 + 6 * s->ops[1]->NC;
@@ -339,53 +415,172 @@ int enqueue_jac(ccalib_solver* s, int buf, double lambda_hint, int ofs, JacLayou
         if (!launch_stereo_lr_sums(s->ops[1]->NC, s->d_blk[1][buf], s->d_cmp[buf], s->lr_jac[buf], s->npad, s->nviews,
                                    part, s->stream))
             return set_error(CCALIB_ERR_UNSUPPORTED, "stereo column count %d is not built in", s->ops[1]->NC);
-        if ((rc = queue_colsum(s, part, s->nblk64, n, ofs))) return rc;
-        ofs += n;
+        if ((rc = queue_colsum(s, part, s->nblk64, n, ofs + L.lr_ofs))) return rc;
     }
-    L.schur_ofs = ofs;
-    int kc = s->kcols();
-    L.nsum = kc * (kc + 1) / 2 + kc;
-    if ((rc = enqueue_schur(s, buf, lambda_hint, ofs))) return rc;
-    ofs += L.nsum;
-    L.end = ofs;
-    if (ofs > ccalib_solver::kRedCap) return set_error(CCALIB_ERR_STATE, "reduction buffer too small");
+    if ((rc = enqueue_schur(s, buf, lambda_hint, ofs + L.schur_ofs, ctrl))) return rc;
+    if (ofs + L.end > kPredOfs) return set_error(CCALIB_ERR_STATE, "reduction buffer too small");
     return CCALIB_OK;
 }
 
-// Unpacks the sums of a finished pass from h_red: shared block U (ns x ns, upper triangle), its
-// gradient, the residual sum and the Schur sums.
-void parse_jac(const ccalib_solver* s, const JacLayout& L, double* U, double* gs, double* err, std::vector<double>& S) {
+// Index of every entry of the shared block U (ns x ns, upper triangle) and of its gradient among the sums of a
+// Jacobian pass (relative to the pass's base offset; -1: structurally zero).  The host unpacks U with it and the
+// device assembles the reduced system with it, so the two cannot disagree on where a number lives.
+void shared_block_index(const ccalib_solver* s, const JacLayout& L, std::vector<int>& Uidx, std::vector<int>& gidx, int err_idx[2]) {
     const int ns = s->ns();
-    std::memset(U, 0, sizeof(double) * ns * ns);
-    std::memset(gs, 0, sizeof(double) * ns);
-    double e = 0;
+    Uidx.assign((size_t)ns * ns, -1);
+    gidx.assign(ns, -1);
     for (int c = 0; c < s->ncams; c++) {
         const ModelOps* m = s->ops[c];
-        const double* r = s->h_red + L.cam_ofs[c];
-        int base = s->ncams == 1 ? 0 : 6 + 18 * c;
+        const int r0 = L.cam_ofs[c], base = s->ncams == 1 ? 0 : 6 + 18 * c;
+        err_idx[c] = r0 + m->NRED_U - 1;
+        if (s->fix_intrinsic) continue;  // the intrinsic columns are not parameters: only the residual sum is kept
         int k = 0;
-        if (s->fix_intrinsic) {  // the intrinsic columns are not parameters: only the residual sum is kept
-            e += r[m->NRED_U - 1];
-            continue;
-        }
         for (int i = 0; i < m->NC; i++)
-            for (int j = i; j < m->NC; j++) U[(size_t)(base + m->col(i)) * ns + base + m->col(j)] = r[k++];
-        for (int i = 0; i < m->NC; i++) gs[base + m->col(i)] = r[k++];
-        e += r[k];
+            for (int j = i; j < m->NC; j++) Uidx[(size_t)(base + m->col(i)) * ns + base + m->col(j)] = r0 + k++;
+        for (int i = 0; i < m->NC; i++) gidx[base + m->col(i)] = r0 + k++;
     }
     if (s->ncams == 2) {
-        const double* r = s->h_red + L.lr_ofs;
-        int k = 0;
+        int k = L.lr_ofs;
         for (int i = 0; i < 6; i++)
-            for (int j = i; j < 6; j++) U[(size_t)i * ns + j] = r[k++];
-        for (int i = 0; i < 6; i++) gs[i] = r[k++];
+            for (int j = i; j < 6; j++) Uidx[(size_t)i * ns + j] = k++;
+        for (int i = 0; i < 6; i++) gidx[i] = k++;
         const ModelOps* m1 = s->ops[1];
         if (!s->fix_intrinsic)
             for (int i = 0; i < m1->NC; i++)
-                for (int b = 0; b < 6; b++) U[(size_t)b * ns + 24 + m1->col(i)] = r[k++];
+                for (int b = 0; b < 6; b++) Uidx[(size_t)b * ns + 24 + m1->col(i)] = k++;
     }
+}
+
+// Builds the index tables for the solver's current column sets and free-parameter mask: the host's (Uidx, gidx,
+// err_idx) and the device's (LmMaps, uploaded).  The free set is the one ccalib_solver_run hands the driver.
+int build_step_maps(ccalib_solver* s) {
+    const JacLayout L = jac_layout(s);
+    shared_block_index(s, L, s->Uidx, s->gidx, s->err_idx);
+    LmMaps& m = s->h_maps;
+    std::memset(&m, 0, sizeof(m));
+    const int ns = s->ns(), kc = s->kcols();
+    m.ns = ns, m.ncams = s->ncams, m.nerr = s->ncams;
+    m.err_idx[0] = s->err_idx[0], m.err_idx[1] = s->err_idx[1];
+    unsigned char smask[kMaxShared];
+    if (s->ncams == 1)
+        std::memcpy(smask, s->imask[0], 18);
+    else {
+        std::memset(smask, 1, 6);
+        if (!s->fix_intrinsic) std::memcpy(smask + 6, s->imask[0], 18), std::memcpy(smask + 24, s->imask[1], 18);
+    }
+    std::vector<int> s2k(ns, -1);
+    for (int k = 0; k < kc; k++)
+        if (s->kcol_to_shared(k) < ns) s2k[s->kcol_to_shared(k)] = k;
+    int nf = 0;
+    bool ok = kc <= kCtrlCols;
+    for (int i = 0; i < ns; i++)
+        if (smask[i]) {
+            m.fidx[nf] = i;
+            m.dc_slot[nf] = s2k[i];
+            ok = ok && s2k[i] >= 0;
+            nf++;
+        }
+    if (!ok) nf = 0;  // a free parameter without a kernel column: the driver reports it; nothing is run ahead
+    m.nf = nf;
+    auto tri = [kc](int a, int b) { return a * kc - a * (a - 1) / 2 + (b - a); };
+    for (int a = 0; a < nf; a++) {
+        const int ia = m.fidx[a], ka = m.dc_slot[a];
+        m.g_idx[a] = s->gidx[ia];
+        m.bs_idx[a] = L.schur_ofs + kc * (kc + 1) / 2 + ka;
+        for (int c = 0; c < nf; c++) {
+            const int ic = m.fidx[c], kb = m.dc_slot[c];
+            m.u_idx[a * nf + c] = s->Uidx[(size_t)std::min(ia, ic) * ns + std::max(ia, ic)];
+            m.s_idx[a * nf + c] = L.schur_ofs + (ka <= kb ? tri(ka, kb) : tri(kb, ka));
+        }
+    }
+    HIP_TRY(hipMemcpy(s->d_maps, &m, sizeof(m), hipMemcpyHostToDevice));
+    return CCALIB_OK;
+}
+
+// Unpacks the sums of a finished pass (r = reduction buffer at the pass's base offset): shared block U (ns x ns,
+// upper triangle), its gradient, the residual sum and the Schur sums.
+void parse_jac(const ccalib_solver* s, const double* r, double* U, double* gs, double* err, std::vector<double>& S) {
+    const int ns = s->ns();
+    const JacLayout L = jac_layout(s);
+    for (int i = 0; i < ns * ns; i++) U[i] = s->Uidx[i] >= 0 ? r[s->Uidx[i]] : 0.;
+    for (int i = 0; i < ns; i++) gs[i] = s->gidx[i] >= 0 ? r[s->gidx[i]] : 0.;
+    double e = 0;
+    for (int c = 0; c < s->ncams; c++) e += r[s->err_idx[c]];
     *err = e;
-    S.assign(s->h_red + L.schur_ofs, s->h_red + L.schur_ofs + L.nsum);
+    S.assign(r + L.schur_ofs, r + L.schur_ofs + L.nsum);
+}
+
+// ---- running one iteration ahead of the host (see lm_step.hpp) ----------------------------------
+
+double next_lambda(double lambda) {  // what ccalib_lm_run announces after an accepted step: one decade down, floor 1e-16
+    const int lg = (int)std::lround(std::log10(lambda));
+    return std::exp(std::max(lg - 1, -16) * std::log(10.));
+}
+int lambda_level(double lambda) { return std::min(32, std::max(0, (int)std::lround(std::log10(lambda)) + 16)); }
+
+bool chain_possible(const ccalib_solver* s) {
+    return s->chain_enabled && s->speculate && !s->cb && s->ncams == 1 && s->run_solve_method == 1 && s->d_ctrl &&
+           s->ops[0]->jac_fused && s->use_fused && s->h_maps.nf > 0;
+}
+
+// Arguments of the k_lm_step that ends a Jacobian pass evaluated at `shared` (by value; a run-ahead iteration
+// takes its trial point from its control block instead): predict the step of damping `lambda` from it.
+void fill_step(const ccalib_solver* s, LmStepArgs& a, int base, double lambda, double prev_err, const double* shared, bool predict) {
+    std::memset(&a, 0, sizeof(a));
+    a.maps = s->d_maps;
+    a.base = base;
+    a.lambda = lambda;
+    a.prev_err = prev_err;
+    if (shared) std::memcpy(a.shared, shared, sizeof(double) * s->ns());
+    a.aspect[0] = s->aspect[0], a.aspect[1] = s->aspect[1];
+    a.same_focal = s->same_focal, a.fix_intrinsic = s->fix_intrinsic;
+    for (int c = 0; c < s->ncams; c++) a.cp0[c] = cam_params(s->intr[c], s->aspect[c]);
+    a.cout = predict ? s->d_ctrl + s->slot_after() : nullptr;
+}
+
+// Enqueues iteration "trial step of damping `lambda` from the point the pass just submitted evaluates", on the
+// assumption that that point is accepted: its kernels take step, cameras and go word from the control block
+// the preceding k_lm_step writes.  `blk_base`: block buffer holding the Jacobian at that point; `pose_base` /
+// `pose_trial`: committed poses then, and where the trial poses go.
+int enqueue_chain(ccalib_solver* s, double lambda, int blk_base, double* pose_base, double* pose_trial) {
+    ccalib_solver::Chain& ch = s->chain;
+    const LmCtrl* ctrl = s->d_ctrl + s->slot;
+    ch.inflight = false;
+    ch.lambda = lambda, ch.lambda_next = next_lambda(lambda);
+    ch.blk_base = blk_base, ch.pose_base = pose_base, ch.pose_trial = pose_trial;
+    int rc;
+    PART_TAKE(npart, s, (size_t)s->nblk64 * 2);
+    DeltaC dc;
+    for (int k = 0; k < I_NMODEL; k++) dc.v[k] = 0;
+    s->ops[0]->backsub(s->d_blk[0][blk_base], s->npad, s->nviews, lambda, dc, pose_base, pose_trial, npart, s->d_pc, s->stream, ctrl);
+    if ((rc = queue_colsum(s, npart, s->nblk64, 2, 0))) return rc;
+    if ((rc = enqueue_jac(s, blk_base ^ 1, ch.lambda_next, 2, pose_trial, ctrl))) return rc;
+    LmStepArgs st;
+    // one more iteration may follow this one (the driver stops at its iteration limit)
+    const bool more = s->commits + 1 < s->run_max_iter && s->level_accepted[lambda_level(ch.lambda_next)];
+    fill_step(s, st, 2, ch.lambda_next, 0., nullptr, more);
+    ch.predicts = more;
+    if ((rc = submit_reduction(s, 2 + jac_layout(s).end, ctrl, &st, &ch.pend))) return rc;
+    ch.inflight = true;
+    s->n_ahead++;
+    return CCALIB_OK;
+}
+
+// Reads what the k_lm_step of the pass in `slot` predicted.
+void read_prediction(ccalib_solver* s, int slot, bool predicted) {
+    const double* h = s->h_red[slot] + kPredOfs;
+    s->pred_go = predicted && h[0] != 0.;
+#ifdef CCALIB_LM_TIMING
+    if (std::getenv("CCALIB_TIMING")) {
+        std::fprintf(stderr, "[lm_step] ticks(10ns):");
+        for (int i = 0; i < (int)h[199]; i++) std::fprintf(stderr, " %.0f", h[200 + i]);
+        std::fprintf(stderr, "\n");
+    }
+#endif
+    if (s->pred_go) {
+        std::memcpy(s->pred_delta, h + 1, sizeof(double) * s->h_maps.nf);
+        std::memcpy(s->pred_shared, h + 1 + s->h_maps.nf, sizeof(double) * s->ns());
+    }
 }
 
 int be_jac(void* user, const double* shared, double lambda_hint, double* U, double* gs, double* err) {
@@ -410,15 +605,33 @@ int be_jac(void* user, const double* shared, double lambda_hint, double* U, doub
         return CCALIB_OK;
     }
     s->spec_valid = false;
+    if (s->chain.inflight) {  // an iteration run ahead from a point the driver did not go to
+        s->chain.inflight = false;
+        s->pc_fresh = false;
+        s->n_ahead_dropped++;
+    }
     store_shared(s, shared);
-    JacLayout L;
-    int rc = enqueue_jac(s, s->cur, lambda_hint, 0, L);
-    if (rc) return rc;
-    if ((rc = finish_reduction(s, L.end))) return rc;
-    parse_jac(s, L, U, gs, err, s->cachedS);
+    int rc;
+    if ((rc = enqueue_jac(s, s->cur, lambda_hint, 0, s->d_pose_cur, nullptr))) return rc;
+    const int n = jac_layout(s).end;
+    Pending p;
+    const bool chain = chain_possible(s) && s->commits < s->run_max_iter && s->level_accepted[lambda_level(lambda_hint)];
+    if (chain_possible(s)) {
+        LmStepArgs st;
+        fill_step(s, st, 0, lambda_hint, HUGE_VAL, shared, chain);
+        if ((rc = submit_reduction(s, n, nullptr, &st, &p))) return rc;
+        // the first step of the run, should the driver take it from here: committed poses are d_pose_cur (the
+        // driver's commit swaps the two pose buffers before it steps)
+        if (chain && (rc = enqueue_chain(s, lambda_hint, s->cur, s->d_pose_cur, s->d_pose_prev))) return rc;
+    } else if ((rc = submit_reduction(s, n, nullptr, nullptr, &p)))
+        return rc;
+    if ((rc = wait_reduction(s, p, n))) return rc;
+    parse_jac(s, s->h_red[p.slot], U, gs, err, s->cachedS);
+    read_prediction(s, p.slot, chain);
     s->cached_lambda = lambda_hint;
     s->have_cached = true;
     s->last_err = *err;
+    if (s->run_first_jac) s->drv_err = *err, s->run_first_jac = false;
     return CCALIB_OK;
 }
 
@@ -428,10 +641,11 @@ int be_reduce(void* user, double lambda, const int* fidx, int nf, double* Ssum, 
     (void)hipGetLastError();  // an error another HIP user of this thread left behind is not ours to report
     int kc = s->kcols(), nsum = kc * (kc + 1) / 2 + kc;
     if (!(s->have_cached && s->cached_lambda == lambda)) {
-        int rc = enqueue_schur(s, s->cur, lambda, 0);
+        int rc = enqueue_schur(s, s->cur, lambda, 0, nullptr);
         if (rc) return rc;
-        if ((rc = finish_reduction(s, nsum))) return rc;
-        s->cachedS.assign(s->h_red, s->h_red + nsum);
+        const double* red;
+        if ((rc = finish_reduction(s, nsum, &red))) return rc;
+        s->cachedS.assign(red, red + nsum);
         s->cached_lambda = lambda;
         s->have_cached = true;
     }
@@ -457,72 +671,121 @@ int be_reduce(void* user, double lambda, const int* fidx, int nf, double* Ssum, 
 // likely to be accepted, from a whole Jacobian pass run ahead into the spare buffer: the driver's
 // next call is then jac() at this same point, which be_jac answers without touching the GPU.
 // A rejected step only costs the extra work; the committed Jacobian stays in buffer `cur`.
+// When the device has already run this very step ahead of the host (same damping, and the step the driver
+// computed is bit for bit the one k_lm_step predicted), its sums are simply waited for.
 int be_step_err(void* user, double lambda, double lambda_next, const int* fidx, int nf, const double* dshared,
                 const double* shared_new, double* dnorm2, double* pnorm2, double* err) {
     ccalib_solver* s = (ccalib_solver*)user;
     s->t_enter = std::chrono::steady_clock::now();
     (void)hipGetLastError();  // an error another HIP user of this thread left behind is not ours to report
     int rc;
-    const int cur = s->cur;
-    std::vector<double> dfull(s->ns(), 0.);
-    for (int a = 0; a < nf; a++) dfull[fidx[a]] = dshared[a];
-    PART_TAKE(npart, s, (size_t)s->nblk64 * 2);
-    if (s->ncams == 1) {
-        DeltaC dc;
-        for (int k = 0; k < I_NMODEL; k++) dc.v[k] = 0;
-        for (int k = 0; k < s->ops[0]->NC; k++) dc.v[k] = dfull[s->ops[0]->col(k)];
-        const bool want_pc = s->ops[0]->jac_fused && s->use_fused;
-        s->ops[0]->backsub(s->d_blk[0][cur], s->npad, s->nviews, lambda, dc, s->d_pose_prev, s->d_pose_cur, npart,
-                           want_pc ? s->d_pc : nullptr, s->stream);
-        s->pc_fresh = want_pc;
-    } else {
-        StereoDelta sd;
-        int kc = s->kcols();
-        for (int k = 0; k < kStereoMaxCols; k++)
-            sd.v[k] = k < kc && s->kcol_to_shared(k) < s->ns() ? dfull[s->kcol_to_shared(k)] : 0.;
-        const bool want_pc = s->ops[0]->jac_fused && s->use_fused;
-        if (!launch_stereo_backsub(s->ops[0]->NC, s->d_blk[0][cur], s->d_blk[1][cur], s->d_cmp[cur], s->lr_jac[cur],
-                                   s->npad, s->nviews, lambda, sd, s->d_pose_prev, s->d_pose_cur, npart,
-                                   want_pc ? s->d_pc : nullptr, s->stream))
-            return set_error(CCALIB_ERR_UNSUPPORTED, "stereo column count %d is not built in", s->ops[0]->NC);
-        s->pc_fresh = want_pc;
-        s->pc3_fresh = false;  // camera 1's poses follow in the composition kernel
-    }
-    if ((rc = queue_colsum(s, npart, s->nblk64, 2, 0))) return rc;
-    store_shared(s, shared_new);
+    const int cur = s->cur, ns = s->ns();
     if (s->steps_since_jac > 0) s->level_accepted[s->last_level] = false;  // a retry: the step before was rejected
-    s->last_level = std::min(32, std::max(0, (int)std::lround(std::log10(lambda)) + 16));
-    const bool ahead = s->speculate && s->level_accepted[s->last_level];
+    s->last_level = lambda_level(lambda);
     s->steps_since_jac++;
     s->spec_valid = false;
     s->have_cached = false;
-    if (ahead) {
-        const int ns = s->ns();
-        JacLayout L;
-        if ((rc = enqueue_jac(s, cur ^ 1, lambda_next, 2, L))) return rc;
-        if ((rc = finish_reduction(s, L.end))) return rc;
+    const double* red = nullptr;
+    bool have_jac = false, predicted = false;
+    int jac_slot = 0;
+
+    ccalib_solver::Chain& ch = s->chain;
+    if (ch.inflight) {
+        const bool match = s->pred_go && ch.lambda == lambda && ch.lambda_next == lambda_next && ch.blk_base == cur &&
+                           ch.pose_base == s->d_pose_prev && ch.pose_trial == s->d_pose_cur && nf == s->h_maps.nf &&
+                           std::memcmp(dshared, s->pred_delta, sizeof(double) * nf) == 0 &&
+                           std::memcmp(shared_new, s->pred_shared, sizeof(double) * ns) == 0;
+        ch.inflight = false;
+        if (match) {
+            // the GPU is already on this step; queue the one after it, then wait for this one's sums
+            const Pending pend = ch.pend;
+            predicted = ch.predicts;
+            store_shared(s, shared_new);
+            s->pc_fresh = true;
+            if (predicted && (rc = enqueue_chain(s, lambda_next, cur ^ 1, s->d_pose_cur, s->d_pose_prev))) return rc;
+            if ((rc = wait_reduction(s, pend, 2 + jac_layout(s).end))) return rc;
+            red = s->h_red[pend.slot];
+            jac_slot = pend.slot;
+            have_jac = true;
+            s->n_ahead_used++;
+        } else {
+            // called off on the device (its go word is 0: nothing ran) or not the step the driver took (it runs to
+            // its end in stream order, into trial buffers that the launches below overwrite)
+            s->pc_fresh = false;
+            s->n_ahead_dropped++;
+        }
+    }
+    if (!have_jac) {
+        std::vector<double> dfull(ns, 0.);
+        for (int a = 0; a < nf; a++) dfull[fidx[a]] = dshared[a];
+        PART_TAKE(npart, s, (size_t)s->nblk64 * 2);
+        if (s->ncams == 1) {
+            DeltaC dc;
+            for (int k = 0; k < I_NMODEL; k++) dc.v[k] = 0;
+            for (int k = 0; k < s->ops[0]->NC; k++) dc.v[k] = dfull[s->ops[0]->col(k)];
+            const bool want_pc = s->ops[0]->jac_fused && s->use_fused;
+            s->ops[0]->backsub(s->d_blk[0][cur], s->npad, s->nviews, lambda, dc, s->d_pose_prev, s->d_pose_cur, npart,
+                               want_pc ? s->d_pc : nullptr, s->stream, nullptr);
+            s->pc_fresh = want_pc;
+        } else {
+            StereoDelta sd;
+            int kc = s->kcols();
+            for (int k = 0; k < kStereoMaxCols; k++)
+                sd.v[k] = k < kc && s->kcol_to_shared(k) < ns ? dfull[s->kcol_to_shared(k)] : 0.;
+            const bool want_pc = s->ops[0]->jac_fused && s->use_fused;
+            if (!launch_stereo_backsub(s->ops[0]->NC, s->d_blk[0][cur], s->d_blk[1][cur], s->d_cmp[cur], s->lr_jac[cur],
+                                       s->npad, s->nviews, lambda, sd, s->d_pose_prev, s->d_pose_cur, npart,
+                                       want_pc ? s->d_pc : nullptr, s->stream))
+                return set_error(CCALIB_ERR_UNSUPPORTED, "stereo column count %d is not built in", s->ops[0]->NC);
+            s->pc_fresh = want_pc;
+            s->pc3_fresh = false;  // camera 1's poses follow in the composition kernel
+        }
+        if ((rc = queue_colsum(s, npart, s->nblk64, 2, 0))) return rc;
+        store_shared(s, shared_new);
+        const bool ahead = s->speculate && s->level_accepted[s->last_level];
+        if (ahead) {
+            if ((rc = enqueue_jac(s, cur ^ 1, lambda_next, 2, s->d_pose_cur, nullptr))) return rc;
+            const int n = 2 + jac_layout(s).end;
+            Pending p;
+            if (chain_possible(s)) {
+                predicted = s->commits < s->run_max_iter && s->level_accepted[lambda_level(lambda_next)];
+                LmStepArgs st;
+                fill_step(s, st, 2, lambda_next, s->committed_err, shared_new, predicted);
+                if ((rc = submit_reduction(s, n, nullptr, &st, &p))) return rc;
+                if (predicted && (rc = enqueue_chain(s, lambda_next, cur ^ 1, s->d_pose_cur, s->d_pose_prev))) return rc;
+            } else if ((rc = submit_reduction(s, n, nullptr, nullptr, &p)))
+                return rc;
+            if ((rc = wait_reduction(s, p, n))) return rc;
+            red = s->h_red[p.slot];
+            jac_slot = p.slot;
+            have_jac = true;
+        } else {
+            // residual pass at the trial point
+            if ((rc = stereo_compose(s, false, cur, s->d_pose_cur))) return rc;
+            for (int c = 0; c < s->ncams; c++) {
+                CamParams cp = cam_params(s->intr[c], s->aspect[c]);
+                PART_TAKE(epart, s, (size_t)s->grid_err);
+                enqueue_err(s, c, cp, epart);
+                if ((rc = queue_colsum(s, epart, s->grid_err, 1, 2 + c))) return rc;
+            }
+            if ((rc = finish_reduction(s, 2 + s->ncams, &red))) return rc;
+            *err = red[2] + (s->ncams == 2 ? red[3] : 0.);
+        }
+    }
+    if (have_jac) {
         s->spec_U.resize((size_t)ns * ns);
         s->spec_gs.resize(ns);
-        parse_jac(s, L, s->spec_U.data(), s->spec_gs.data(), &s->spec_err, s->spec_S);
+        parse_jac(s, red + 2, s->spec_U.data(), s->spec_gs.data(), &s->spec_err, s->spec_S);
+        read_prediction(s, jac_slot, predicted);
         s->spec_lambda = lambda_next;
         std::memcpy(s->spec_shared, shared_new, sizeof(double) * ns);
         s->spec_valid = true;
         *err = s->spec_err;
-    } else {
-        // residual pass at the trial point
-        if ((rc = stereo_compose(s, false, cur))) return rc;
-        for (int c = 0; c < s->ncams; c++) {
-            CamParams cp = cam_params(s->intr[c], s->aspect[c]);
-            PART_TAKE(epart, s, (size_t)s->grid_err);
-            enqueue_err(s, c, cp, epart);
-            if ((rc = queue_colsum(s, epart, s->grid_err, 1, 2 + c))) return rc;
-        }
-        if ((rc = finish_reduction(s, 2 + s->ncams))) return rc;
-        *err = s->h_red[2] + (s->ncams == 2 ? s->h_red[3] : 0.);
     }
-    *dnorm2 = s->h_red[0];
-    *pnorm2 = s->h_red[1];
+    *dnorm2 = red[0];
+    *pnorm2 = red[1];
     s->last_err = *err;
+    s->drv_err = *err;
     return CCALIB_OK;
 }
 
@@ -530,6 +793,8 @@ int be_commit(void* user) {
     ccalib_solver* s = (ccalib_solver*)user;
     std::swap(s->d_pose_prev, s->d_pose_cur);  // the next step rewrites every trial pose
     // (the cached Schur sums belong to the committed Jacobian and stay valid)
+    s->committed_err = s->drv_err;             // what the driver now compares trial points with
+    s->commits++;
     return CCALIB_OK;
 }
 
@@ -660,11 +925,18 @@ int ccalib_solver_create(ccalib_solver** out, int device, int ncams, int nviews,
         HIP_TRY(hipMalloc(&s->d_pc3, sizeof(double) * kPoseConstStride * nviews));
         for (int b = 0; b < 2; b++) HIP_TRY(hipMalloc(&s->d_cmp[b], sizeof(double) * kCmpRows * s->npad));
     }
-    HIP_TRY(hipMalloc(&s->d_red, sizeof(double) * ccalib_solver::kRedCap));
-    // coherent (uncached on the device side): the host reads these while the stream that writes them is still running
-    HIP_TRY(hipHostMalloc(&s->h_red, sizeof(double) * ccalib_solver::kRedCap, hipHostMallocCoherent));
-    HIP_TRY(hipHostMalloc(&s->h_flag, sizeof(unsigned long long), hipHostMallocCoherent));
-    *s->h_flag = 0;
+    for (int q = 0; q < 2; q++) {
+        HIP_TRY(hipMalloc(&s->d_red[q], sizeof(double) * ccalib_solver::kRedCap));
+        // coherent (uncached on the device side): the host reads these while the stream that writes them is still running
+        HIP_TRY(hipHostMalloc(&s->h_red[q], sizeof(double) * ccalib_solver::kRedCap, hipHostMallocCoherent));
+        HIP_TRY(hipHostMalloc(&s->h_flag[q], sizeof(unsigned long long), hipHostMallocCoherent));
+        *s->h_flag[q] = 0;
+    }
+    HIP_TRY(hipMalloc(&s->d_ctrl, sizeof(LmCtrl) * 2));
+    HIP_TRY(hipMemset(s->d_ctrl, 0, sizeof(LmCtrl) * 2));
+    HIP_TRY(hipMalloc(&s->d_maps, sizeof(LmMaps)));
+    std::memset(&s->h_maps, 0, sizeof(LmMaps));
+    if (const char* e = std::getenv("CCALIB_NO_CHAIN")) s->chain_enabled = std::atoi(e) == 0;
     HIP_TRY(hipMalloc(&s->d_counter, sizeof(unsigned)));
     HIP_TRY(hipMemset(s->d_counter, 0, sizeof(unsigned)));
     s->segs.nseg = 0;
@@ -681,10 +953,13 @@ void ccalib_solver_destroy(ccalib_solver* s) {
     (void)hipFree(s->d_obj), (void)hipFree(s->d_off), (void)hipFree(s->d_img[0]), (void)hipFree(s->d_img[1]);
     (void)hipFree(s->d_pose_prev), (void)hipFree(s->d_pose_cur), (void)hipFree(s->d_pose3);
     for (int b = 0; b < 2; b++) (void)hipFree(s->d_cmp[b]), (void)hipFree(s->d_blk[0][b]), (void)hipFree(s->d_blk[1][b]);
-    (void)hipFree(s->d_pc), (void)hipFree(s->d_pc3), (void)hipFree(s->d_part), (void)hipFree(s->d_red);
+    (void)hipFree(s->d_pc), (void)hipFree(s->d_pc3), (void)hipFree(s->d_ctrl), (void)hipFree(s->d_maps);
+    for (int q = 0; q < 2; q++) {
+        (void)hipFree(s->d_part[q]), (void)hipFree(s->d_red[q]);
+        if (s->h_red[q]) (void)hipHostFree(s->h_red[q]);
+        if (s->h_flag[q]) (void)hipHostFree(s->h_flag[q]);
+    }
     (void)hipFree(s->d_status), (void)hipFree(s->d_pose_init1), (void)hipFree(s->d_parked_view), (void)hipFree(s->d_parked_state);
-    if (s->h_red) (void)hipHostFree(s->h_red);
-    if (s->h_flag) (void)hipHostFree(s->h_flag);
     (void)hipFree(s->d_counter);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
@@ -729,9 +1004,12 @@ int ccalib_solver_set_start(ccalib_solver* s, const double* intr, const unsigned
     {
         size_t need = part_capacity(s);
         if (need > s->part_cap) {
-            if (s->d_part) (void)hipFree(s->d_part);
-            s->d_part = nullptr, s->part_cap = 0;
-            HIP_TRY(hipMalloc(&s->d_part, sizeof(double) * need));
+            for (int q = 0; q < 2; q++) {
+                if (s->d_part[q]) (void)hipFree(s->d_part[q]);
+                s->d_part[q] = nullptr;
+            }
+            s->part_cap = 0;
+            for (int q = 0; q < 2; q++) HIP_TRY(hipMalloc(&s->d_part[q], sizeof(double) * need));
             s->part_cap = need;
         }
         s->part_used = 0;
@@ -745,6 +1023,10 @@ int ccalib_solver_set_start(ccalib_solver* s, const double* intr, const unsigned
     if (lr) std::memcpy(s->lr, lr, sizeof(double) * 6);
     if (rt) HIP_TRY(hipMemcpy(s->d_pose_cur, rt, sizeof(double) * 6 * s->nviews, hipMemcpyHostToDevice));
     s->poses_ready[0] = s->poses_ready[1] = false;  // the LM loop takes the pose buffers over
+    int rc = build_step_maps(s);
+    if (rc) return rc;
+    s->chain.inflight = false;
+    s->pred_go = false;
     s->started = true;
     s->pc_fresh = s->pc3_fresh = false;
     s->have_cached = false;
@@ -773,9 +1055,9 @@ static InitArgs init_args(const ccalib_solver* s, int cam) {
 // Sums n doubles over the ranks of a multi-GPU run (no-op for a single rank).
 static int allreduce_host(ccalib_solver* s, double* buf, int n) {
     if (s->comm) {
-        HIP_TRY(hipMemcpyAsync(s->d_red, buf, sizeof(double) * n, hipMemcpyHostToDevice, s->stream));
-        NCCL_TRY(ncclAllReduce(s->d_red, s->d_red, n, ncclDouble, ncclSum, s->comm, s->stream));
-        HIP_TRY(hipMemcpyAsync(buf, s->d_red, sizeof(double) * n, hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipMemcpyAsync(s->d_red[0], buf, sizeof(double) * n, hipMemcpyHostToDevice, s->stream));
+        NCCL_TRY(ncclAllReduce(s->d_red[0], s->d_red[0], n, ncclDouble, ncclSum, s->comm, s->stream));
+        HIP_TRY(hipMemcpyAsync(buf, s->d_red[0], sizeof(double) * n, hipMemcpyDeviceToHost, s->stream));
         HIP_TRY(hipStreamSynchronize(s->stream));
     } else if (s->cb) {
         int rc = s->cb(s->cb_user, buf, n);
@@ -987,8 +1269,21 @@ int ccalib_solver_run(ccalib_solver* s, int term_type, int max_iter, double eps,
         }
     }
     s->t_wait = s->t_enqueue = 0;
+    // what the run-ahead needs to know of the driver's plans: its solver and its iteration limit (CvLevMarq::init)
+    s->run_solve_method = solve_method;
+    s->run_max_iter = (term_type & CCALIB_TERM_COUNT) ? std::min(std::max(max_iter, 1), 1000) : 30;
+    s->commits = 0;
+    s->run_first_jac = true;
+    s->chain.inflight = false;
+    s->pred_go = false;
     int rc = ccalib_lm_run(&be, s, shared, smask, term_type, max_iter, eps, solve_method, stats);
     store_shared(s, shared);
+    if (s->chain.inflight) {  // the driver stopped on its convergence test with an iteration still running ahead
+        s->chain.inflight = false;
+        s->pc_fresh = false;
+        s->n_ahead_dropped++;
+        HIP_TRY(hipStreamSynchronize(s->stream));
+    }
     if (std::getenv("CCALIB_TIMING") && stats)
         std::fprintf(stderr, "[ccalib] run: total %.3f ms, enqueue %.3f ms, polling %.3f ms, other host %.3f ms\n", stats->device_ms,
                      s->t_enqueue * 1e3, s->t_wait * 1e3, stats->device_ms - (s->t_enqueue + s->t_wait) * 1e3);
@@ -1009,6 +1304,12 @@ int ccalib_solver_get(ccalib_solver* s, double* intr, double* rt, double* lr, do
     return CCALIB_OK;
 }
 
+int ccalib_solver_counters(ccalib_solver* s, long long out[3]) {
+    if (!s || !out) return set_error(CCALIB_ERR_ARG, "counters: bad arguments");
+    out[0] = s->n_ahead, out[1] = s->n_ahead_used, out[2] = s->n_ahead_dropped;
+    return CCALIB_OK;
+}
+
 int ccalib_solver_num_shared(ccalib_solver* s, int* ns) {
     if (!s || !ns) return set_error(CCALIB_ERR_ARG, "num_shared: bad arguments");
     *ns = s->ns();
@@ -1021,7 +1322,7 @@ int ccalib_solver_eval_error(ccalib_solver* s, double* err) {
     (void)hipGetLastError();  // an error another HIP user of this thread left behind is not ours to report
     s->t_enter = std::chrono::steady_clock::now();
     int rc;
-    if ((rc = stereo_compose(s, false, s->cur))) return rc;
+    if ((rc = stereo_compose(s, false, s->cur, s->d_pose_cur))) return rc;
     for (int c = 0; c < s->ncams; c++) {
         CamParams cp = cam_params(s->intr[c], s->aspect[c]);
         if (s->aspect[c] != 0) cp.fx = cp.fy * s->aspect[c];
@@ -1029,8 +1330,9 @@ int ccalib_solver_eval_error(ccalib_solver* s, double* err) {
         enqueue_err(s, c, cp, epart);
         if ((rc = queue_colsum(s, epart, s->grid_err, 1, c))) return rc;
     }
-    if ((rc = finish_reduction(s, s->ncams))) return rc;
-    *err = s->h_red[0] + (s->ncams == 2 ? s->h_red[1] : 0.);
+    const double* red;
+    if ((rc = finish_reduction(s, s->ncams, &red))) return rc;
+    *err = red[0] + (s->ncams == 2 ? red[1] : 0.);
     return CCALIB_OK;
 }
 
@@ -1100,7 +1402,7 @@ int ccalib_solver_time_kernels(ccalib_solver* s, int reps, double ms[3]) {
             if (which == 0)
                 m->jac_shared(a, cp, s->grid_red, tpart, s->stream);
             else if (which == 1 && fused)
-                m->jac_fused(a, cp, s->d_pc, s->grid_fused, s->d_blk[0][s->cur], tpart, s->stream);
+                m->jac_fused(a, cp, s->d_pc, s->grid_fused, s->d_blk[0][s->cur], tpart, s->stream, nullptr, 0);
             else if (which == 1)
                 m->jac_view(a, cp, s->grid_view, s->d_blk[0][s->cur], s->npad, s->stream);
             else

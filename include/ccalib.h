@@ -250,6 +250,16 @@ int ccalib_solver_use_callback(ccalib_solver* s, ccalib_allreduce_fn fn, void* u
 int ccalib_solver_run(ccalib_solver* s, int term_type, int max_iter, double eps, int solve_method,
                       ccalib_stats* stats);
 
+/*
+ * How often ccalib_solver_run kept the GPU one iteration ahead of the host state machine (CvLevMarq waits for the
+ * sums of every pass before the next can start; here the device predicts the host's next step -- same IEEE
+ * operations in the same order -- and the kernels of that step are already queued; the host uses them only when
+ * its own step is bit for bit the predicted one, so results never depend on it).  out[0] iterations enqueued
+ * ahead, out[1] of them used by the driver, out[2] dropped (step rejected, convergence reached, or no match).
+ * Since the solver was created.  CCALIB_NO_CHAIN=1 in the environment turns the mechanism off.
+ */
+int ccalib_solver_counters(ccalib_solver* s, long long out[3]);
+
 /* Results: intr ncams x 18, rt nviews x 6, lr 6 (NULL ok), err = sum of squared residuals. */
 int ccalib_solver_get(ccalib_solver* s, double* intr, double* rt, double* lr, double* err);
 

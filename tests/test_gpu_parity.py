@@ -406,6 +406,28 @@ def test_one_and_three_tile_workgroups_agree_bitwise(pkg, synth, monkeypatch):
     assert np.array_equal(o1["intr"], o3["intr"]) and np.array_equal(o1["rt"], o3["rt"]) and o1["err"] == o3["err"]
 
 
+def test_running_ahead_of_the_host_changes_nothing(pkg, synth, monkeypatch):
+    """The GPU runs one LM iteration ahead of the host state machine (the device predicts the host's next step);
+    the host adopts that work only when its own step is bit for bit the predicted one, so a run with the mechanism
+    must equal a run without it bit for bit -- and the mechanism must actually engage."""
+    obj = synth.chessboard(9, 6, 25.0)
+    ms = synth.make_views(obj, 30_011, 2024)
+    intr, mask, aspect, rt = _start(pkg, synth, ms)
+    outs = []
+    for off in ("1", "0"):
+        monkeypatch.setenv("CCALIB_NO_CHAIN", off)
+        s = pkg.Solver(obj, ms.img)
+        s.set_start(intr, mask, rt)
+        st = s.run(criteria=(3, 25, 1e-13))
+        outs.append((st, s.get(), s.counters()))
+        s.close()
+    (st0, o0, c0), (st1, o1, c1) = outs
+    assert c0["ahead"] == 0
+    assert c1["used"] >= st1["iters"] - 3, (c1, st1)          # all but the first steps and the ones after a rejection
+    assert st0["iters"] == st1["iters"] and st0["err_passes"] == st1["err_passes"]
+    assert np.array_equal(o0["intr"], o1["intr"]) and np.array_equal(o0["rt"], o1["rt"]) and o0["err"] == o1["err"]
+
+
 def test_noise_free_recovery_10k_views(pkg, synth):
     obj = synth.chessboard(9, 6, 25.0)
     ms = synth.make_views(obj, 10_000, 4242, noise=0.0)
