@@ -66,6 +66,20 @@ enum { ORC_NINTRINSIC = 18 };
 /* solver choices for the damped normal equations */
 enum { ORC_SOLVE_LU = 0, ORC_SOLVE_SVD = 1, ORC_SOLVE_CHOLESKY = 2 };
 
+/*
+ * What-if switches for the two details of OpenCV 4.1.0 that were restated from memory and could not be checked
+ * against its text (all 0 = the restatement the product is tested against).  They exist so that the size of the
+ * effect can be measured (tests/test_oracle_variants.py): a maintainer with a real OpenCV then knows what a
+ * mismatch from either cause would look like.
+ *   ORC_VARIANT_PP_HALF_SIZE     cvInitIntrinsicParams2D seeds the principal point at (w/2, h/2) instead of
+ *                                ((w-1)/2, (h-1)/2)
+ *   ORC_VARIANT_SAME_FOCAL_MASK  CALIB_SAME_FOCAL_LENGTH also masks camera 1's fx, fy out of the solve instead of
+ *                                only overwriting them from camera 0 before every pass
+ */
+enum { ORC_VARIANT_PP_HALF_SIZE = 1, ORC_VARIANT_SAME_FOCAL_MASK = 2 };
+extern int orc_variants;
+void orc_set_variants(int bits);
+
 /* ---- geometry ---------------------------------------------------------- */
 /* cvRodrigues2, vector -> matrix.  J (may be NULL) is 3x9: J[i*9+k] = dR[k]/dr[i]. */
 void orc_rodrigues_v2m(const double r[3], double R[9], double J[27]);

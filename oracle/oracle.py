@@ -66,6 +66,14 @@ def _d(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
+VARIANT_PP_HALF_SIZE, VARIANT_SAME_FOCAL_MASK = 1, 2
+
+
+def set_variants(bits: int):
+    """What-if switches for the two recalled details of OpenCV 4.1.0 (see calib_oracle.h); 0 = the restatement."""
+    lib().orc_set_variants(C.c_int(bits))
+
+
 def rodrigues_v2m(r):
     R, J = np.zeros(9), np.zeros(27)
     lib().orc_rodrigues_v2m(_p(_d(r)), _p(R), _p(J))

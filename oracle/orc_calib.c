@@ -29,6 +29,9 @@
 
 #define NI ORC_NINTRINSIC
 
+int orc_variants = 0;
+void orc_set_variants(int bits) { orc_variants = bits; }
+
 /* ---- per-view 6x6 elimination shared by the mono and stereo schur paths ---------------- */
 
 typedef struct {
@@ -552,6 +555,8 @@ double orc_stereo_calibrate(int nviews, const int* npts, const double* obj, cons
             for (int j = 12; j < 16; j++) imask[j] = imask[NI + j] = 0;
         if (flags & ORC_FIX_TAUX_TAUY)
             for (int j = 16; j < 18; j++) imask[j] = imask[NI + j] = 0;
+        if ((flags & ORC_SAME_FOCAL_LENGTH) && (orc_variants & ORC_VARIANT_SAME_FOCAL_MASK))
+            imask[NI] = imask[NI + 1] = 0; /* what-if: camera 1's focal lengths are not unknowns */
     }
 
     /* initial poses: per-view per-camera PnP, relative pose by per-component median */

@@ -203,6 +203,10 @@ int orc_init_intrinsic_params_2d(int nviews, const int* npts, const double* obj,
     double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 1};
     a[2] = (!width) ? 0.5 : (width - 1) * 0.5;
     a[5] = (!height) ? 0.5 : (height - 1) * 0.5;
+    if (orc_variants & ORC_VARIANT_PP_HALF_SIZE) { /* what-if: principal point seeded at w/2, h/2 */
+        a[2] = width * 0.5;
+        a[5] = height * 0.5;
+    }
     double* Am = (double*)malloc(sizeof(double) * 4 * nviews);
     double* bm = (double*)malloc(sizeof(double) * 2 * nviews);
     int pos = 0;
