@@ -147,10 +147,9 @@ def test_intrinsic_guess_and_fixed_subsets(pkg, orc, synth):
         got = pkg.calibrate_camera(obj, ms.img, (640, 480), K=K0, dist=np.zeros(nd), ndist=nd, flags=flags, criteria=crit)
         ref = orc.calibrate_camera(obj, ms.img, (640, 480), K=K0, dist=np.zeros(nd), ndist=nd, flags=flags,
                                    criteria=crit, schur=False)
-        tol = 1e-6 if nd < 8 else 1e-5   # the 8-coefficient model is nearly degenerate on this data
         assert abs(got["rms"] - ref["rms"]) <= 1e-6 * ref["rms"]
-        assert np.allclose(got["K"], ref["K"], rtol=tol)
-        assert np.abs(got["rvecs"] - ref["rvecs"]).max() < 10 * tol
+        assert np.allclose(got["K"], ref["K"], rtol=1e-6)     # also for the nearly degenerate 8-coefficient model
+        assert np.abs(got["rvecs"] - ref["rvecs"]).max() < 1e-6
 
 
 @pytest.mark.parametrize("seed", range(8))
@@ -181,7 +180,16 @@ def test_random_flag_subsets_match_oracle(pkg, orc, synth, seed):
     got = pkg.calibrate_camera(obj, ms.img, (640, 480), K=K0, dist=d0, ndist=nd, flags=flags, criteria=crit)
     ref = orc.calibrate_camera(obj, ms.img, (640, 480), K=K0, dist=d0, ndist=nd, flags=flags, criteria=crit, schur=False)
     free_rational = nd == 8 and not all(flags & f for f in (pkg.CALIB_FIX_K4, pkg.CALIB_FIX_K5, pkg.CALIB_FIX_K6))
-    tol = 2e-5 if free_rational else 1e-6      # numerator and denominator polynomials nearly cancel on this data
+    tol = 1e-6
+    if free_rational:
+        # numerator and denominator polynomials nearly cancel on this data: the minimum is flat along one direction
+        # and two correct solvers end at visibly different points of it.  The yardstick is the oracle itself --
+        # its dense and its Schur solver on the same input -- and the HIP path may differ from the dense one by no
+        # more than a few times what the oracle's two solvers differ by.
+        alt = orc.calibrate_camera(obj, ms.img, (640, 480), K=K0, dist=d0, ndist=nd, flags=flags, criteria=crit, schur=True)
+        spread = max(np.abs(alt["K"] - ref["K"]).max() / np.abs(ref["K"]).max(), np.abs(alt["rvecs"] - ref["rvecs"]).max() / 10)
+        tol = max(1e-6, 4 * spread)
+        assert tol <= 2e-5, tol
     assert abs(got["rms"] - ref["rms"]) <= 1e-6 * ref["rms"], hex(flags)
     assert abs(got["iters"] - ref["iters"]) <= 1, hex(flags)
     assert np.allclose(got["K"], ref["K"], rtol=tol, atol=1e-9), hex(flags)
@@ -284,12 +292,22 @@ def test_stereo_other_column_sets_and_ragged_views(pkg, orc, synth, case):
         i2 = [st.img2[i][k] for i, k in enumerate(keep)]
     got = pkg.stereo_calibrate(objs, i1, i2, K1, None, K2, None, (640, 480), flags, criteria=crit)
     ref = orc.stereo_calibrate(objs, i1, i2, K1, None, K2, None, (640, 480), flags, criteria=crit, schur=False)
-    assert abs(got["rms"] - ref["rms"]) <= REL * ref["rms"]
+    tol = REL
+    if case == "rational12":
+        # The 12-coefficient model is nearly degenerate on this data and the run stops at its iteration limit, in
+        # the middle of a walk along a flat valley: two correct solvers are then visibly apart.  The yardstick is
+        # the oracle's own dense-vs-Schur spread on this input; the HIP path may be a few times that from the dense
+        # result, and the yardstick itself must stay small.
+        alt = orc.stereo_calibrate(objs, i1, i2, K1, None, K2, None, (640, 480), flags, criteria=crit, schur=True)
+        spread = max([abs(alt["rms"] - ref["rms"]) / ref["rms"]] +
+                     [np.abs(alt[k] - ref[k]).max() / np.abs(ref[k]).max() for k in ("K1", "K2", "R", "T")])
+        tol = max(REL, 4 * spread)
+        assert tol <= 1e-5, tol
+    assert abs(got["rms"] - ref["rms"]) <= tol * ref["rms"]
     assert abs(got["iters"] - ref["iters"]) <= 1
-    tol = 1e-4 if case == "rational12" else REL       # the 8-coefficient model is nearly degenerate on this data
     for key in ("K1", "K2", "R", "T"):
         assert np.allclose(got[key], ref[key], rtol=tol, atol=tol * np.abs(ref[key]).max()), key
-    assert np.abs(got["rt"] - ref["rt"])[:, :3].max() < 100 * tol
+    assert np.abs(got["rt"] - ref["rt"])[:, :3].max() < 2 * tol
     if case == "aspect8":
         assert got["K1"][0, 0] / got["K1"][1, 1] == pytest.approx(K1[0, 0] / K1[1, 1], rel=1e-12)
 
@@ -334,7 +352,7 @@ def test_extreme_shapes_one_view_and_a_1200_point_board(pkg, orc, synth):
         got = pkg.calibrate_camera(obj, ms.img, (640, 480), K=K0, dist=np.zeros(5), flags=flags, criteria=crit)
         ref = orc.calibrate_camera(obj, ms.img, (640, 480), K=K0, dist=np.zeros(5), flags=flags, criteria=crit, schur=False)
         assert abs(got["rms"] - ref["rms"]) <= 1e-6 * ref["rms"]
-        assert np.allclose(got["K"], ref["K"], rtol=1e-5)          # one to three views determine the camera poorly
+        assert np.allclose(got["K"], ref["K"], rtol=1e-6)
         assert abs(got["iters"] - ref["iters"]) <= 1
     big = synth.chessboard(40, 30, 4.0)
     ms = synth.make_views(big, 5, 77)

