@@ -118,6 +118,15 @@ struct ccalib_solver {
     bool have_cached = false;
     double cached_lambda = 0;
     std::vector<double> cachedS;  // kernel-column space, see reduce()
+    // A second set for the damping one decade up, taken in the same pass when the run has settled into
+    // "first trial rejected, retry accepted" (the reference's stereoCalibrate flag set does): the retry's
+    // reduce() is then answered without a pass of its own.
+    bool have_cached2 = false;
+    double cached_lambda2 = 0;
+    std::vector<double> cachedS2;
+    bool spec_have2 = false;
+    double spec_lambda2 = 0;
+    std::vector<double> spec_S2;
 
     // Jacobian pass run ahead at the last trial point (valid until the next pass or step)
     bool speculate = true;
@@ -296,7 +305,7 @@ size_t part_capacity(const ccalib_solver* s) {
     int kc = s->kcols();
     for (int c = 0; c < s->ncams; c++)
         n += (size_t)std::max(s->grid_fused * kTileViews, s->grid_red) * s->ops[c]->NRED_U + 64 + (size_t)std::max(s->grid_red, s->grid_err) + 64;
-    n += (size_t)s->nblk64 * (kc * (kc + 1) / 2 + kc) + 64;  // Schur sums
+    n += 2 * ((size_t)s->nblk64 * (kc * (kc + 1) / 2 + kc) + 64);  // Schur sums, for up to two dampings in one pass
     n += (size_t)s->nblk64 * 2 + 64;                          // step norms
     if (s->ncams == 2) n += (size_t)s->nblk64 * (27 + 6 * s->ops[1]->NC) + 64;
     return n;
@@ -383,7 +392,9 @@ JacLayout jac_layout(const ccalib_solver* s) {
 // land in the reduction buffer from `ofs` on, laid out as jac_layout() says.  The pass evaluates camera 0 at the
 // poses `pose` (records in d_pc must match them).  By-value parameters (the solver's current intrinsics and
 // relative pose) are used unless `ctrl` names the control block of a run-ahead iteration.
-int enqueue_jac(ccalib_solver* s, int buf, double lambda_hint, int ofs, const double* pose, const LmCtrl* ctrl) {
+// lambda_extra != 0: a second set of Schur sums, for that damping, follows the first at offset jac_layout().end.
+int enqueue_jac(ccalib_solver* s, int buf, double lambda_hint, int ofs, const double* pose, const LmCtrl* ctrl,
+                double lambda_extra = 0.) {
     int rc = stereo_compose(s, true, buf, pose);
     if (rc) return rc;
     const JacLayout L = jac_layout(s);
@@ -418,7 +429,8 @@ int enqueue_jac(ccalib_solver* s, int buf, double lambda_hint, int ofs, const do
         if ((rc = queue_colsum(s, part, s->nblk64, n, ofs + L.lr_ofs))) return rc;
     }
     if ((rc = enqueue_schur(s, buf, lambda_hint, ofs + L.schur_ofs, ctrl))) return rc;
-    if (ofs + L.end > kPredOfs) return set_error(CCALIB_ERR_STATE, "reduction buffer too small");
+    if (lambda_extra != 0. && (rc = enqueue_schur(s, buf, lambda_extra, ofs + L.end, ctrl))) return rc;
+    if (ofs + L.end + (lambda_extra != 0. ? L.nsum : 0) > kPredOfs) return set_error(CCALIB_ERR_STATE, "reduction buffer too small");
     return CCALIB_OK;
 }
 
@@ -518,6 +530,14 @@ double next_lambda(double lambda) {  // what ccalib_lm_run announces after an ac
 }
 int lambda_level(double lambda) { return std::min(32, std::max(0, (int)std::lround(std::log10(lambda)) + 16)); }
 
+// The damping whose Schur sums are worth taking along with those for `lambda`: one decade up, when the last
+// trial at `lambda`'s level was rejected and the last one a decade up accepted; 0 otherwise.
+double retry_lambda(const ccalib_solver* s, double lambda) {
+    const int lv = lambda_level(lambda);
+    if (!s->speculate || lv >= 32 || s->level_accepted[lv] || !s->level_accepted[lv + 1]) return 0.;
+    return std::exp((lv + 1 - 16) * std::log(10.));  // the value ccalib_lm_run passes for that exponent
+}
+
 bool chain_possible(const ccalib_solver* s) {
     return s->chain_enabled && s->speculate && !s->cb && s->ncams == 1 && s->run_solve_method == 1 && s->d_ctrl &&
            s->ops[0]->jac_fused && s->use_fused && s->h_maps.nf > 0;
@@ -602,6 +622,8 @@ int be_jac(void* user, const double* shared, double lambda_hint, double* U, doub
         s->cachedS = s->spec_S;
         s->cached_lambda = s->spec_lambda;
         s->have_cached = true;
+        s->have_cached2 = s->spec_have2;
+        if (s->spec_have2) s->cachedS2 = s->spec_S2, s->cached_lambda2 = s->spec_lambda2;
         return CCALIB_OK;
     }
     s->spec_valid = false;
@@ -612,8 +634,10 @@ int be_jac(void* user, const double* shared, double lambda_hint, double* U, doub
     }
     store_shared(s, shared);
     int rc;
-    if ((rc = enqueue_jac(s, s->cur, lambda_hint, 0, s->d_pose_cur, nullptr))) return rc;
-    const int n = jac_layout(s).end;
+    const double lam2 = retry_lambda(s, lambda_hint);
+    if ((rc = enqueue_jac(s, s->cur, lambda_hint, 0, s->d_pose_cur, nullptr, lam2))) return rc;
+    const JacLayout L0 = jac_layout(s);
+    const int n = L0.end + (lam2 != 0. ? L0.nsum : 0);
     Pending p;
     const bool chain = chain_possible(s) && s->commits < s->run_max_iter && s->level_accepted[lambda_level(lambda_hint)];
     if (chain_possible(s)) {
@@ -630,6 +654,8 @@ int be_jac(void* user, const double* shared, double lambda_hint, double* U, doub
     read_prediction(s, p.slot, chain);
     s->cached_lambda = lambda_hint;
     s->have_cached = true;
+    s->have_cached2 = lam2 != 0.;
+    if (lam2 != 0.) s->cachedS2.assign(s->h_red[p.slot] + L0.end, s->h_red[p.slot] + L0.end + L0.nsum), s->cached_lambda2 = lam2;
     s->last_err = *err;
     if (s->run_first_jac) s->drv_err = *err, s->run_first_jac = false;
     return CCALIB_OK;
@@ -640,6 +666,11 @@ int be_reduce(void* user, double lambda, const int* fidx, int nf, double* Ssum, 
     s->t_enter = std::chrono::steady_clock::now();
     (void)hipGetLastError();  // an error another HIP user of this thread left behind is not ours to report
     int kc = s->kcols(), nsum = kc * (kc + 1) / 2 + kc;
+    if (!(s->have_cached && s->cached_lambda == lambda) && s->have_cached2 && s->cached_lambda2 == lambda) {
+        s->cachedS.swap(s->cachedS2);  // the sums taken along for the retry
+        std::swap(s->cached_lambda, s->cached_lambda2);
+        s->have_cached = true;
+    }
     if (!(s->have_cached && s->cached_lambda == lambda)) {
         int rc = enqueue_schur(s, s->cur, lambda, 0, nullptr);
         if (rc) return rc;
@@ -688,6 +719,7 @@ int be_step_err(void* user, double lambda, double lambda_next, const int* fidx, 
     const double* red = nullptr;
     bool have_jac = false, predicted = false;
     int jac_slot = 0;
+    double lam2 = 0.;  // damping of a second set of Schur sums taken along with the pass run ahead
 
     ccalib_solver::Chain& ch = s->chain;
     if (ch.inflight) {
@@ -744,8 +776,10 @@ int be_step_err(void* user, double lambda, double lambda_next, const int* fidx, 
         store_shared(s, shared_new);
         const bool ahead = s->speculate && s->level_accepted[s->last_level];
         if (ahead) {
-            if ((rc = enqueue_jac(s, cur ^ 1, lambda_next, 2, s->d_pose_cur, nullptr))) return rc;
-            const int n = 2 + jac_layout(s).end;
+            lam2 = retry_lambda(s, lambda_next);
+            if ((rc = enqueue_jac(s, cur ^ 1, lambda_next, 2, s->d_pose_cur, nullptr, lam2))) return rc;
+            const JacLayout L0 = jac_layout(s);
+            const int n = 2 + L0.end + (lam2 != 0. ? L0.nsum : 0);
             Pending p;
             if (chain_possible(s)) {
                 predicted = s->commits < s->run_max_iter && s->level_accepted[lambda_level(lambda_next)];
@@ -778,6 +812,12 @@ int be_step_err(void* user, double lambda, double lambda_next, const int* fidx, 
         parse_jac(s, red + 2, s->spec_U.data(), s->spec_gs.data(), &s->spec_err, s->spec_S);
         read_prediction(s, jac_slot, predicted);
         s->spec_lambda = lambda_next;
+        s->spec_have2 = lam2 != 0.;
+        if (lam2 != 0.) {
+            const JacLayout L0 = jac_layout(s);
+            s->spec_S2.assign(red + 2 + L0.end, red + 2 + L0.end + L0.nsum);
+            s->spec_lambda2 = lam2;
+        }
         std::memcpy(s->spec_shared, shared_new, sizeof(double) * ns);
         s->spec_valid = true;
         *err = s->spec_err;
@@ -1030,6 +1070,7 @@ int ccalib_solver_set_start(ccalib_solver* s, const double* intr, const unsigned
     s->started = true;
     s->pc_fresh = s->pc3_fresh = false;
     s->have_cached = false;
+    s->have_cached2 = false;
     s->spec_valid = false;
     s->steps_since_jac = 0;
     for (bool& b : s->level_accepted) b = true;
@@ -1375,6 +1416,7 @@ int ccalib_solver_reduce(ccalib_solver* s, double lambda, double* Ssum, double* 
         for (int k = 0; k < kc; k++)
             if (s->kcol_to_shared(k) == i) fidx.push_back(i);
     s->have_cached = false;
+    s->have_cached2 = false;
     s->spec_valid = false;
     return be_reduce(s, lambda, fidx.data(), (int)fidx.size(), Ssum, bsum);
 }
@@ -1419,6 +1461,7 @@ int ccalib_solver_time_kernels(ccalib_solver* s, int reps, double ms[3]) {
     }
     (void)hipEventDestroy(e0), (void)hipEventDestroy(e1);
     s->have_cached = false;
+    s->have_cached2 = false;
     s->spec_valid = false;
     return CCALIB_OK;
 }

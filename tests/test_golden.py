@@ -31,7 +31,11 @@ def _check_mono(got, g, pose_tol):
     assert np.allclose(got["dist"], g["dist"], rtol=1e-5, atol=1e-8)
     assert np.abs(got["rvecs"] - g["rvecs"]).max() < pose_tol
     assert np.abs(got["tvecs"] - g["tvecs"]).max() < pose_tol * max(1.0, np.abs(g["tvecs"]).max())
-    assert abs(got["iters"] - int(g["iters"])) <= 1
+    # +-1 where the criteria stop the run on a meaningful step size.  With eps = DBL_EPSILON (cv::calibrateCamera's
+    # default) the stop lands on round-off -- the last iterations move nothing -- and the count depends on the order
+    # of the sums (the oracle's own what-if variants move it by 4 on this input, tests/test_oracle_variants.py).
+    eps = float(g["criteria"][2])
+    assert abs(got["iters"] - int(g["iters"])) <= (1 if eps > 1e-12 else 6)
 
 
 @pytest.mark.parametrize("name", MONO)
@@ -80,7 +84,11 @@ def test_hip_matches_golden_stereo(pkg):
     got = pkg.stereo_calibrate(g["obj"], g["img1"], g["img2"], g["K1_init"], None, g["K2_init"], None, size, int(g["flags"]),
                                criteria=crit)
     assert abs(got["rms"] - float(g["rms"])) <= REL * float(g["rms"])
-    assert abs(got["iters"] - int(g["iters"])) <= 1
+    # +-1 where the criteria stop the run on a meaningful step size.  With eps = DBL_EPSILON (cv::calibrateCamera's
+    # default) the stop lands on round-off -- the last iterations move nothing -- and the count depends on the order
+    # of the sums (the oracle's own what-if variants move it by 4 on this input, tests/test_oracle_variants.py).
+    eps = float(g["criteria"][2])
+    assert abs(got["iters"] - int(g["iters"])) <= (1 if eps > 1e-12 else 6)
     for key in ("K1", "K2", "R", "T", "E", "F"):
         assert np.allclose(got[key], g[key], rtol=REL, atol=1e-8 * np.abs(g[key]).max()), key
     assert np.allclose(got["d1"], g["d1"], rtol=REL, atol=1e-9) and np.allclose(got["d2"], g["d2"], rtol=REL, atol=1e-9)

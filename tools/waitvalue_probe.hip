@@ -88,6 +88,35 @@ int main() {
         std::printf("%s  parked behind hipStreamWaitValue64 (%d kernel%s) round trip   %.2f us\n", chain == 1 ? "B" : "C", chain,
                     chain == 1 ? "" : "s", us);
     }
+    // E: as A, but every round is a long kernel (~150 us of work on all CUs) followed by the signal: the host
+    //    turn-around after real work = round time - kernel time (events)
+    {
+        const int n = 9000;
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(k_work, dim3(2048), dim3(256), 0, st, sink, n);
+        CK(hipStreamSynchronize(st));
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < 20; i++) hipLaunchKernelGGL(k_work, dim3(2048), dim3(256), 0, st, sink, n);
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const double kernel_us = ms * 1e3 / 20;
+        unsigned long long seq = *flag;
+        const int r2 = 300;
+        auto t0 = now();
+        for (int i = 0; i < r2; i++) {
+            ctrl[0] = i;
+            hipLaunchKernelGGL(k_work, dim3(2048), dim3(256), 0, st, sink, n);
+            hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, st, flag, ++seq, ctrl, sink);
+            wait_flag(seq);
+        }
+        double us = std::chrono::duration<double, std::micro>(now() - t0).count() / r2;
+        std::printf("E  long kernel (%.1f us back to back) + signal, launched on demand: %.2f us per round -> turn-around %.2f us\n",
+                    kernel_us, us, us - kernel_us);
+    }
     // D: four dependent kernels launched back to back, no host in between (the floor for a chain of four)
     {
         unsigned long long seq = *flag;
