@@ -71,6 +71,11 @@ struct ccalib_solver {
     // The per-view blocks exist twice: `cur` holds the Jacobian the driver is stepping from, the other
     // one receives the pass run ahead at a trial point (see be_step_err).
     int cur = 0;
+    short* d_sums_tab = nullptr;                            // stereo: where the products of the sums kernel go
+    short* d_view_tab = nullptr;                            // stereo: the same for the one-lane-per-view kernel
+    bool sums_old = false;
+    bool sums_quad = false;                                 // stereo: four lanes per view in the sums kernel
+    int sums_rows = 0;                                      // stereo: partial-sum rows (workgroups) of the sums kernel
     double* d_cmp[2] = {nullptr, nullptr};                  // stereo: per-view composition Jacobians (SoA), per buffer
     double* d_blk[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [camera][buffer]
     double* d_pc = nullptr;  // nviews x kPoseConstStride: poses in the form the fused Jacobian kernel reads
@@ -305,9 +310,10 @@ size_t part_capacity(const ccalib_solver* s) {
     int kc = s->kcols();
     for (int c = 0; c < s->ncams; c++)
         n += (size_t)std::max(s->grid_fused * kTileViews, s->grid_red) * s->ops[c]->NRED_U + 64 + (size_t)std::max(s->grid_red, s->grid_err) + 64;
-    n += 2 * ((size_t)s->nblk64 * (kc * (kc + 1) / 2 + kc) + 64);  // Schur sums, for up to two dampings in one pass
-    n += (size_t)s->nblk64 * 2 + 64;                          // step norms
-    if (s->ncams == 2) n += (size_t)s->nblk64 * (27 + 6 * s->ops[1]->NC) + 64;
+    const size_t srows = s->ncams == 2 ? s->sums_rows : s->nblk64;
+    n += 2 * (srows * (kc * (kc + 1) / 2 + kc) + 64);  // Schur sums, for up to two dampings in one pass
+    n += (size_t)s->nblk64 * 2 + 64;                   // step norms
+    if (s->ncams == 2) n += srows * (27 + 6 * s->ops[1]->NC) + 64;
     return n;
 }
 
@@ -359,15 +365,40 @@ int stereo_compose(ccalib_solver* s, bool with_jac, int buf, const double* pose1
 
 // Launches the Schur-sum kernels of buffer `buf` for `lambda` and appends their column sums to the reduction
 // at `ofs`.  Layout appended: upper triangle (kc(kc+1)/2) then right-hand side (kc), kc = kernel columns.
-int enqueue_schur(ccalib_solver* s, int buf, double lambda, int ofs, const LmCtrl* ctrl) {
+int enqueue_schur(ccalib_solver* s, int buf, double lambda, int ofs, const LmCtrl* ctrl, int lr_ofs = -1) {
     int kc = s->kcols(), nsum = kc * (kc + 1) / 2 + kc;
-    PART_TAKE(part, s, (size_t)s->nblk64 * nsum);
-    if (s->ncams == 1)
+    if (s->ncams == 1) {
+        PART_TAKE(part, s, (size_t)s->nblk64 * nsum);
         s->ops[0]->schur(s->d_blk[0][buf], s->npad, s->nviews, lambda, part, s->stream, ctrl);
-    else if (!launch_stereo_schur(s->ops[0]->NC, s->d_blk[0][buf], s->d_blk[1][buf], s->d_cmp[buf], s->lr_jac[buf],
-                                  s->npad, s->nviews, lambda, part, s->stream))
-        return set_error(CCALIB_ERR_UNSUPPORTED, "stereo column count %d is not built in", s->ops[0]->NC);
-    return queue_colsum(s, part, s->nblk64, nsum, ofs);
+        return queue_colsum(s, part, s->nblk64, nsum, ofs);
+    }
+    // stereo: one kernel takes the Schur sums and, with lr_ofs >= 0, the sums that enter the shared block through
+    // the relative pose: B^T V3 B (21), B^T ge3 (6), W3 B (NC1 x 6)
+    const int nlr = 27 + 6 * s->ops[1]->NC;
+    PART_TAKE(part, s, (size_t)s->sums_rows * nsum);
+    double* part_lr = nullptr;
+    if (lr_ofs >= 0) {
+        PART_TAKE(pl, s, (size_t)s->sums_rows * nlr);
+        part_lr = pl;
+    }
+    bool ok;
+    if (s->sums_quad)
+        ok = launch_stereo_sums(s->ops[0]->NC, s->d_blk[0][buf], s->d_blk[1][buf], s->d_cmp[buf], s->lr_jac[buf], s->npad,
+                                s->nviews, lambda, s->d_sums_tab, s->sums_rows, part, part_lr, s->stream);
+    else if (!s->sums_old)
+        ok = launch_stereo_view_sums(s->ops[0]->NC, s->d_blk[0][buf], s->d_blk[1][buf], s->d_cmp[buf], s->lr_jac[buf], s->npad,
+                                     s->nviews, lambda, s->d_view_tab, part, part_lr, s->stream);
+    else {
+        ok = launch_stereo_schur(s->ops[0]->NC, s->d_blk[0][buf], s->d_blk[1][buf], s->d_cmp[buf], s->lr_jac[buf], s->npad,
+                                 s->nviews, lambda, part, s->stream);
+        if (ok && part_lr)
+            ok = launch_stereo_lr_sums(s->ops[1]->NC, s->d_blk[1][buf], s->d_cmp[buf], s->lr_jac[buf], s->npad, s->nviews,
+                                       part_lr, s->stream);
+    }
+    if (!ok) return set_error(CCALIB_ERR_UNSUPPORTED, "stereo column count %d is not built in", s->ops[0]->NC);
+    int rc = queue_colsum(s, part, s->sums_rows, nsum, ofs);
+    if (!rc && part_lr) rc = queue_colsum(s, part_lr, s->sums_rows, nlr, lr_ofs);
+    return rc;
 }
 
 // Where the sums of one Jacobian pass sit in the reduction buffer, relative to the pass's base offset.
@@ -419,16 +450,7 @@ int enqueue_jac(ccalib_solver* s, int buf, double lambda_hint, int ofs, const do
             m->jac_view(a, cp, s->grid_view, s->d_blk[c][buf], s->npad, s->stream);
         }
     }
-    if (s->ncams == 2) {
-        // shared-block pieces that involve the relative pose: B^T V3 B (21), B^T ge3 (6), W3 B (NC1 x 6)
-        int n = 27 + 6 * s->ops[1]->NC;
-        PART_TAKE(part, s, (size_t)s->nblk64 * n);
-        if (!launch_stereo_lr_sums(s->ops[1]->NC, s->d_blk[1][buf], s->d_cmp[buf], s->lr_jac[buf], s->npad, s->nviews,
-                                   part, s->stream))
-            return set_error(CCALIB_ERR_UNSUPPORTED, "stereo column count %d is not built in", s->ops[1]->NC);
-        if ((rc = queue_colsum(s, part, s->nblk64, n, ofs + L.lr_ofs))) return rc;
-    }
-    if ((rc = enqueue_schur(s, buf, lambda_hint, ofs + L.schur_ofs, ctrl))) return rc;
+    if ((rc = enqueue_schur(s, buf, lambda_hint, ofs + L.schur_ofs, ctrl, s->ncams == 2 ? ofs + L.lr_ofs : -1))) return rc;
     if (lambda_extra != 0. && (rc = enqueue_schur(s, buf, lambda_extra, ofs + L.end, ctrl))) return rc;
     if (ofs + L.end + (lambda_extra != 0. ? L.nsum : 0) > kPredOfs) return set_error(CCALIB_ERR_STATE, "reduction buffer too small");
     return CCALIB_OK;
@@ -720,6 +742,7 @@ int be_step_err(void* user, double lambda, double lambda_next, const int* fidx, 
     bool have_jac = false, predicted = false;
     int jac_slot = 0;
     double lam2 = 0.;  // damping of a second set of Schur sums taken along with the pass run ahead
+    bool stereo_composed = false;
 
     ccalib_solver::Chain& ch = s->chain;
     if (ch.inflight) {
@@ -765,12 +788,19 @@ int be_step_err(void* user, double lambda, double lambda_next, const int* fidx, 
             for (int k = 0; k < kStereoMaxCols; k++)
                 sd.v[k] = k < kc && s->kcol_to_shared(k) < ns ? dfull[s->kcol_to_shared(k)] : 0.;
             const bool want_pc = s->ops[0]->jac_fused && s->use_fused;
+            // a residual pass follows unless the next Jacobian pass is run ahead (which composes with derivatives):
+            // camera 1's trial poses then come out of this kernel too
+            const bool compose_here = !(s->speculate && s->level_accepted[s->last_level]);
+            StereoLR lr_new;
+            for (int i = 0; i < 6; i++) lr_new.v[i] = shared_new[i];
             if (!launch_stereo_backsub(s->ops[0]->NC, s->d_blk[0][cur], s->d_blk[1][cur], s->d_cmp[cur], s->lr_jac[cur],
                                        s->npad, s->nviews, lambda, sd, s->d_pose_prev, s->d_pose_cur, npart,
-                                       want_pc ? s->d_pc : nullptr, s->stream))
+                                       want_pc ? s->d_pc : nullptr, lr_new, compose_here ? s->d_pose3 : nullptr,
+                                       compose_here ? s->d_pc3 : nullptr, s->stream))
                 return set_error(CCALIB_ERR_UNSUPPORTED, "stereo column count %d is not built in", s->ops[0]->NC);
             s->pc_fresh = want_pc;
-            s->pc3_fresh = false;  // camera 1's poses follow in the composition kernel
+            s->pc3_fresh = compose_here;
+            stereo_composed = compose_here;
         }
         if ((rc = queue_colsum(s, npart, s->nblk64, 2, 0))) return rc;
         store_shared(s, shared_new);
@@ -795,7 +825,7 @@ int be_step_err(void* user, double lambda, double lambda_next, const int* fidx, 
             have_jac = true;
         } else {
             // residual pass at the trial point
-            if ((rc = stereo_compose(s, false, cur, s->d_pose_cur))) return rc;
+            if (!stereo_composed && (rc = stereo_compose(s, false, cur, s->d_pose_cur))) return rc;
             for (int c = 0; c < s->ncams; c++) {
                 CamParams cp = cam_params(s->intr[c], s->aspect[c]);
                 PART_TAKE(epart, s, (size_t)s->grid_err);
@@ -992,6 +1022,8 @@ void ccalib_solver_destroy(ccalib_solver* s) {
     if (s->comm) ncclCommDestroy(s->comm);
     (void)hipFree(s->d_obj), (void)hipFree(s->d_off), (void)hipFree(s->d_img[0]), (void)hipFree(s->d_img[1]);
     (void)hipFree(s->d_pose_prev), (void)hipFree(s->d_pose_cur), (void)hipFree(s->d_pose3);
+    (void)hipFree(s->d_sums_tab);
+    (void)hipFree(s->d_view_tab);
     for (int b = 0; b < 2; b++) (void)hipFree(s->d_cmp[b]), (void)hipFree(s->d_blk[0][b]), (void)hipFree(s->d_blk[1][b]);
     (void)hipFree(s->d_pc), (void)hipFree(s->d_pc3), (void)hipFree(s->d_ctrl), (void)hipFree(s->d_maps);
     for (int q = 0; q < 2; q++) {
@@ -1040,6 +1072,27 @@ int ccalib_solver_set_start(ccalib_solver* s, const double* intr, const unsigned
                 HIP_TRY(hipMalloc(&s->d_blk[c][b], sizeof(double) * (size_t)m->NBLK * s->npad));
             }
         s->ops[c] = m;
+    }
+    if (s->ncams == 2) {
+        const int n = stereo_sums_table(m->NC, nullptr);
+        if (!n) return set_error(CCALIB_ERR_UNSUPPORTED, "stereo column count %d is not built in", m->NC);
+        std::vector<short> tab(n);
+        stereo_sums_table(m->NC, tab.data());
+        if (!s->d_sums_tab) HIP_TRY(hipMalloc(&s->d_sums_tab, sizeof(short) * 4 * (quad_nlr(12) + quad_ngram(12))));
+        HIP_TRY(hipMemcpy(s->d_sums_tab, tab.data(), sizeof(short) * n, hipMemcpyHostToDevice));
+        {
+            std::vector<short> vt(stereo_view_table(m->NC, nullptr));
+            if (!stereo_view_table(m->NC, vt.data())) return set_error(CCALIB_ERR_STATE, "stereo sum table is inconsistent");
+            if (!s->d_view_tab) HIP_TRY(hipMalloc(&s->d_view_tab, sizeof(short) * stereo_view_table(12, nullptr)));
+            HIP_TRY(hipMemcpy(s->d_view_tab, vt.data(), sizeof(short) * vt.size(), hipMemcpyHostToDevice));
+            const char* eo = std::getenv("CCALIB_SUMS_OLD");
+            s->sums_old = eo && std::atoi(eo) != 0;
+        }
+        // Few views: four lanes per view fill the chip where one lane per view would leave most of it idle.
+        // Many views: one lane per view issues a quarter of the instructions.
+        const char* e = std::getenv("CCALIB_SUMS_QUAD");
+        s->sums_quad = e ? std::atoi(e) != 0 : s->nblk64 < 512;
+        s->sums_rows = s->sums_quad ? stereo_sums_rows(s->nviews) : s->nblk64;
     }
     {
         size_t need = part_capacity(s);

@@ -12,6 +12,10 @@
 //     U_LR,LR += B^T V3 B    g_LR += B^T ge3        U_LR,cam1 += (W3 B)^T
 #include "stereo_kernels.hpp"
 
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
 #include "device_math.hpp"
 #include "kernels.hpp"
 
@@ -321,10 +325,443 @@ __global__ __launch_bounds__(64) void k_stereo_schur(const double* blk0, const d
     red.flush();
 }
 
+// ---- Schur sums and relative-pose sums, four lanes per view ----------------------------------------
+// The rows of the view's coupling block W (6 relative-pose rows, NC rows per camera) and its gradient ge are dealt
+// out to the four lanes of a quad: every lane builds V = V0 + A^T V3 A and its Cholesky factor for itself, prepares
+// and forward-solves only its own rows, and the products of the Gram matrix Z Z^T are taken between a lane's rows
+// and the rows of the lane 0, 1 or 2 places further round the quad (DPP quad_perm).  A wavefront carries 16 views;
+// per-lane products go through LDS transposed, 16 at a time, where lane 4p+a adds up the 16 views' contributions of
+// product p in quad position a, in a fixed order, and keeps the sum over the wavefront's views in a register.
+//
+// Every row is prepared by one formula,  w = raw0 + x A,  x = c V3 + e:
+//   relative-pose row r:  c = column r of B           (x A = B^T V3 A row r,  x B = B^T V3 B row r)
+//   gradient row:         e = ge3, raw0 = ge0         (x A + raw0 = ge,       x B = B^T ge3)
+//   camera-0 row i:       raw0 = W0[i]
+//   camera-1 row i:       e = W3[i]                   (x A = W3 A row i,      x B = W3 B row i)
+// The gradient is carried as one more row (index kc), so Z[i].y needs no code of its own.
+template <int CTRL>
+__device__ __forceinline__ double quad_take(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+constexpr int kStageRow = 68;  // doubles between products in the LDS stage: quads of one half-wavefront on distinct banks
+
+template <int NC, bool WITH_LR>
+__global__ __launch_bounds__(64) void k_stereo_sums(const double* __restrict__ blk0, const double* __restrict__ blk1,
+                                                    const double* __restrict__ cmp, StereoLR lr, int npad, int nviews,
+                                                    int ngroups, double lambda, const short* __restrict__ tab,
+                                                    double* __restrict__ part, double* __restrict__ part_lr) {
+    constexpr int NB = 27 + 6 * NC, SC = quad_sc(NC), NS = quad_nslot(NC), KC = 6 + 2 * NC;
+    constexpr int LRV = quad_nlr(NC), P0 = WITH_LR ? LRV : 0, P = P0 + quad_ngram(NC), NCH = (P + kQuadChunk - 1) / kQuadChunk;
+    constexpr int NSUM = KC * (KC + 1) / 2 + KC, NOUT = 27 + 6 * NC;
+    const int lane = threadIdx.x, a = lane & 3;
+    __shared__ double stage[kQuadChunk * kStageRow];
+    double acc[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; k++) acc[k] = 0.;
+    double R2[9];
+    {
+        double r2[3] = {lr.v[0], lr.v[1], lr.v[2]};
+        rodrigues<false>(r2, R2, nullptr);
+    }
+    // parks product K of this lane; after the last product of a chunk the chunk is summed over the 16 views
+    auto push = [&](auto kk, double val) {
+        constexpr int K = decltype(kk)::value, slot = K % kQuadChunk, ch = K / kQuadChunk;
+        stage[slot * kStageRow + lane] = val;
+        if constexpr (slot == kQuadChunk - 1 || K == P - 1) {
+            __builtin_amdgcn_wave_barrier();
+            const double* col = stage + (lane >> 2) * kStageRow + a;
+            double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+            for (int q = 0; q < 16; q += 4) s0 += col[4 * q], s1 += col[4 * q + 4], s2 += col[4 * q + 8], s3 += col[4 * q + 12];
+            if ((lane >> 2) <= slot) acc[ch] += (s0 + s1) + (s2 + s3);
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+    for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const int v = g * 16 + (lane >> 2);
+        const bool live = v < nviews;
+        const int vv = live ? v : nviews - 1;
+        double Ar[9], V3[6][6], Vu[21];
+        {
+            double u[21];
+#pragma unroll
+            for (int k = 0; k < 21; k++) u[k] = blk1[blk_index(NB, k, vv)];
+            unpack_sym6(u, V3);
+        }
+#pragma unroll
+        for (int k = 0; k < 9; k++) Ar[k] = cmp[(size_t)k * npad + vv];
+        // V = V0 + A^T V3 A, A = diag(Ar, R2), block by block
+        {
+            double Pm[3][3], Q[3][3], T[3][3];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    Pm[i][j] = V3[i][0] * Ar[j] + V3[i][1] * Ar[3 + j] + V3[i][2] * Ar[6 + j];
+                    Q[i][j] = V3[i][3] * R2[j] + V3[i][4] * R2[3 + j] + V3[i][5] * R2[6 + j];
+                    T[i][j] = V3[3 + i][3] * R2[j] + V3[3 + i][4] * R2[3 + j] + V3[3 + i][5] * R2[6 + j];
+                }
+#pragma unroll
+            for (int p = 0; p < 3; p++)
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    if (q >= p) {
+                        Vu[tri6(p, q)] = blk0[blk_index(NB, tri6(p, q), vv)] + (Ar[p] * Pm[0][q] + Ar[3 + p] * Pm[1][q] + Ar[6 + p] * Pm[2][q]);
+                        Vu[tri6(3 + p, 3 + q)] =
+                            blk0[blk_index(NB, tri6(3 + p, 3 + q), vv)] + (R2[p] * T[0][q] + R2[3 + p] * T[1][q] + R2[6 + p] * T[2][q]);
+                    }
+                    Vu[tri6(p, 3 + q)] = blk0[blk_index(NB, tri6(p, 3 + q), vv)] + (Ar[p] * Q[0][q] + Ar[3 + p] * Q[1][q] + Ar[6 + p] * Q[2][q]);
+                }
+        }
+        double L[21], invd[6];
+        const bool use = chol6(Vu, lambda, L, invd) && live;
+        __builtin_amdgcn_sched_barrier(0);
+        double Z[NS][6];
+        // x -> x A (+ raw0), forward-solved into Z[s]; x B pushed when the relative-pose sums are wanted
+        auto finish_row = [&](auto ss, const double x[6], const double raw0[6], auto lr_slot) {
+            constexpr int S = decltype(ss)::value, LS = decltype(lr_slot)::value;
+            double w[6];
+            __builtin_amdgcn_sched_barrier(0);  // keeps the next slots' loads from piling up ahead of this one
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                w[j] = raw0[j] + (x[0] * Ar[j] + x[1] * Ar[3 + j] + x[2] * Ar[6 + j]);
+                w[3 + j] = raw0[3 + j] + (x[3] * R2[j] + x[4] * R2[3 + j] + x[5] * R2[6 + j]);
+            }
+            chol6_fwd(L, invd, w);
+#pragma unroll
+            for (int b = 0; b < 6; b++) Z[S][b] = use ? w[b] : 0.;
+            if constexpr (WITH_LR && LS >= 0) {
+                double Brr[9], Btr[9];
+#pragma unroll
+                for (int k = 0; k < 9; k++) Brr[k] = cmp[(size_t)(9 + k) * npad + vv], Btr[k] = cmp[(size_t)(18 + k) * npad + vv];
+                static_for<0, 6>([&](auto jj) {
+                    constexpr int j = decltype(jj)::value;
+                    double o = j < 3 ? x[0] * Brr[j] + x[1] * Brr[3 + j] + x[2] * Brr[6 + j] + x[3] * Btr[j] + x[4] * Btr[3 + j] + x[5] * Btr[6 + j]
+                                     : x[j];
+                    push(std::integral_constant<int, 6 * LS + j>{}, live ? o : 0.);
+                });
+            }
+        };
+        const double zero6[6] = {0, 0, 0, 0, 0, 0};
+        {   // slot 0: relative-pose rows 0..3
+            const int rc = a < 3 ? a : 2;
+            double c[6], x[6];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                double br = cmp[(size_t)(9 + 3 * k + rc) * npad + vv], bt = cmp[(size_t)(18 + 3 * k + rc) * npad + vv];
+                c[k] = a < 3 ? br : 0.;
+                c[3 + k] = a < 3 ? bt : (k == 0 ? 1. : 0.);
+            }
+#pragma unroll
+            for (int j = 0; j < 6; j++)
+                x[j] = c[0] * V3[0][j] + c[1] * V3[1][j] + c[2] * V3[2][j] + c[3] * V3[3][j] + c[4] * V3[4][j] + c[5] * V3[5][j];
+            finish_row(std::integral_constant<int, 0>{}, x, zero6, std::integral_constant<int, 0>{});
+        }
+        {   // slot 1: relative-pose rows 4, 5, the gradient, nothing
+            double x[6], raw0[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                double g3 = blk1[blk_index(NB, 21 + j, vv)], g0 = blk0[blk_index(NB, 21 + j, vv)];
+                x[j] = a == 0 ? V3[4][j] : a == 1 ? V3[5][j] : a == 2 ? g3 : 0.;
+                raw0[j] = a == 2 ? g0 : 0.;
+            }
+            finish_row(std::integral_constant<int, 1>{}, x, raw0, std::integral_constant<int, 1>{});
+        }
+        static_for<0, SC>([&](auto ii) {  // camera-0 rows
+            constexpr int I = decltype(ii)::value;
+            const int i = 4 * I + a, ic = i < NC ? i : NC - 1;
+            double raw0[6];
+#pragma unroll
+            for (int b = 0; b < 6; b++) {
+                double wv = blk0[blk_index(NB, 27 + 6 * ic + b, vv)];
+                raw0[b] = i < NC ? wv : 0.;
+            }
+            finish_row(std::integral_constant<int, 2 + I>{}, zero6, raw0, std::integral_constant<int, -1>{});
+        });
+        static_for<0, SC>([&](auto ii) {  // camera-1 rows
+            constexpr int I = decltype(ii)::value;
+            const int i = 4 * I + a, ic = i < NC ? i : NC - 1;
+            double x[6];
+#pragma unroll
+            for (int b = 0; b < 6; b++) {
+                double wv = blk1[blk_index(NB, 27 + 6 * ic + b, vv)];
+                x[b] = i < NC ? wv : 0.;
+            }
+            finish_row(std::integral_constant<int, 2 + SC + I>{}, x, zero6, std::integral_constant<int, 2 + I>{});
+        });
+        // Gram products: own rows, then against the lane one place on, then two places on
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, NS>([&](auto s1) {
+            constexpr int S1 = decltype(s1)::value;
+            static_for<S1, NS>([&](auto s2) {
+                constexpr int S2 = decltype(s2)::value;
+                double d = 0;
+#pragma unroll
+                for (int b = 0; b < 6; b++) d += Z[S1][b] * Z[S2][b];
+                push(std::integral_constant<int, P0 + quad_gram_index(NC, 0, S1, S2)>{}, d);
+            });
+        });
+        static_for<0, NS>([&](auto s2) {
+            constexpr int S2 = decltype(s2)::value;
+            double o[6];
+#pragma unroll
+            for (int b = 0; b < 6; b++) o[b] = quad_take<0x39>(Z[S2][b]);
+            static_for<0, NS>([&](auto s1) {
+                constexpr int S1 = decltype(s1)::value;
+                double d = 0;
+#pragma unroll
+                for (int b = 0; b < 6; b++) d += Z[S1][b] * o[b];
+                push(std::integral_constant<int, P0 + quad_gram_index(NC, 1, S1, S2)>{}, d);
+            });
+        });
+        static_for<0, NS>([&](auto s2) {
+            constexpr int S2 = decltype(s2)::value;
+            double o[6];
+#pragma unroll
+            for (int b = 0; b < 6; b++) o[b] = quad_take<0x4E>(Z[S2][b]);
+            static_for<0, S2 + 1>([&](auto s1) {
+                constexpr int S1 = decltype(s1)::value;
+                double d = 0;
+#pragma unroll
+                for (int b = 0; b < 6; b++) d += Z[S1][b] * o[b];
+                push(std::integral_constant<int, P0 + quad_gram_index(NC, 2, S1, S2)>{}, d);
+            });
+        });
+    }
+    // lane 4p+a holds, per chunk, the wavefront's sum of product p in quad position a; the table says where it goes
+    const short* t = tab + (WITH_LR ? 0 : 4 * LRV);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) {
+        const int p = ch * kQuadChunk + (lane >> 2);
+        if (p < P) {
+            const int e = t[4 * p + a];
+            if (e >= 0)
+                part[(size_t)blockIdx.x * NSUM + e] = acc[ch];
+            else if (e <= -2)
+                part_lr[(size_t)blockIdx.x * NOUT + (-2 - e)] = acc[ch];
+        }
+    }
+}
+
+// ---- Schur sums and relative-pose sums, one lane per view, in three passes over the Gram matrix ----------
+// Holding all of Z = W L^-T (kc x 6 per view) at once takes more registers than two wavefronts per SIMD leave, and
+// with one wavefront per SIMD nothing hides the latency of the FP64 chains.  So Z is held a part at a time:
+//   pass A: relative-pose rows and camera-0 rows     -> blocks (LR,LR) (LR,c0) (c0,c0) and their right-hand sides
+//   pass B: camera-1 rows replace camera-0 rows      -> blocks (LR,c1) (c1,c1) and theirs
+//   pass C: camera-0 rows again, one at a time       -> block (c0,c1)
+// Products leave in that order; `dst` (stereo_view_table) says where each belongs in the packed sums.
+struct TabReducer {  // LaneReducer with all 64 lanes adding and a destination table
+    double* sm;
+    const short* dst;
+    double *out0, *out1;
+    int k = 0, base = 0;
+    __device__ __forceinline__ TabReducer(double* sm_, const short* dst_, double* o0, double* o1) : sm(sm_), dst(dst_), out0(o0), out1(o1) {}
+    __device__ __forceinline__ void push(double v) {
+        sm[k * 65 + (threadIdx.x & 63)] = v;
+        if (++k == 32) flush();
+    }
+    __device__ __forceinline__ void flush() {
+        if (k == 0) return;
+        const int lane = threadIdx.x & 63;
+        __builtin_amdgcn_wave_barrier();
+        const double* row = sm + (lane & 31) * 65 + (lane >> 5) * 32;
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+        for (int j = 0; j < 32; j += 4) s0 += row[j], s1 += row[j + 1], s2 += row[j + 2], s3 += row[j + 3];
+        double s = (s0 + s1) + (s2 + s3);
+        s += __shfl_xor(s, 32);
+        if (lane < k) {
+            const int e = dst[base + lane];
+            if (e >= 0)
+                out0[e] = s;
+            else
+                out1[-2 - e] = s;
+        }
+        __builtin_amdgcn_wave_barrier();
+        base += k;
+        k = 0;
+    }
+};
+
+template <int NC, bool WITH_LR>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_stereo_view_sums(
+    const double* __restrict__ blk0, const double* __restrict__ blk1, const double* __restrict__ cmp, StereoLR lr, int npad,
+    int nviews, double lambda, const short* __restrict__ dst, double* __restrict__ part, double* __restrict__ part_lr) {
+    constexpr int NB = 27 + 6 * NC, KC = 6 + 2 * NC, NSUM = KC * (KC + 1) / 2 + KC, NOUT = 27 + 6 * NC;
+    const int v = blockIdx.x * 64 + threadIdx.x;
+    const bool live = v < nviews;
+    const int vv = live ? v : nviews - 1;
+    __shared__ double sm[32 * 65];
+    TabReducer red(sm, dst + (WITH_LR ? 0 : NOUT), part + (size_t)blockIdx.x * NSUM, part_lr + (size_t)blockIdx.x * NOUT);
+    double Ar[9], R2[9];
+    {
+        double r2[3] = {lr.v[0], lr.v[1], lr.v[2]}, Rv[9];
+        rodrigues<false>(r2, Rv, nullptr);
+#pragma unroll
+        for (int k = 0; k < 9; k++)  // the same in every lane: kept in scalar registers
+            R2[k] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(Rv[k])),
+                                     __builtin_amdgcn_readfirstlane(__double2loint(Rv[k])));
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) Ar[k] = cmp[(size_t)k * npad + vv];
+    auto times_A = [&](const double w[6], double o[6]) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            o[j] = w[0] * Ar[j] + w[1] * Ar[3 + j] + w[2] * Ar[6 + j];
+            o[3 + j] = w[3] * R2[j] + w[4] * R2[3 + j] + w[5] * R2[6 + j];
+        }
+    };
+    double ZL[6][6], Vu[21], y[6];
+    {
+        double V3[6][6], ge3[6], M[6][6], Brr[9], Btr[9];
+        {
+            double u[21];
+#pragma unroll
+            for (int k = 0; k < 21; k++) u[k] = blk1[blk_index(NB, k, vv)];
+            unpack_sym6(u, V3);
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++) ge3[k] = blk1[blk_index(NB, 21 + k, vv)];
+#pragma unroll
+        for (int k = 0; k < 9; k++) Brr[k] = cmp[(size_t)(9 + k) * npad + vv], Btr[k] = cmp[(size_t)(18 + k) * npad + vv];
+        auto times_B = [&](const double w[6], double o[6]) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                o[j] = w[0] * Brr[j] + w[1] * Brr[3 + j] + w[2] * Brr[6 + j] + w[3] * Btr[j] + w[4] * Btr[3 + j] + w[5] * Btr[6 + j];
+                o[3 + j] = w[3 + j];
+            }
+        };
+        if constexpr (WITH_LR) {  // B^T V3 B (upper), B^T ge3, W3 B
+            double N[6][6];
+#pragma unroll
+            for (int r = 0; r < 6; r++) times_B(V3[r], N[r]);
+#pragma unroll
+            for (int p = 0; p < 6; p++)
+#pragma unroll
+                for (int q = p; q < 6; q++) {
+                    double d = p < 3 ? Brr[p] * N[0][q] + Brr[3 + p] * N[1][q] + Brr[6 + p] * N[2][q] + Btr[p] * N[3][q] +
+                                           Btr[3 + p] * N[4][q] + Btr[6 + p] * N[5][q]
+                                     : N[p][q];
+                    red.push(live ? d : 0.);
+                }
+            double g[6];
+            times_B(ge3, g);
+#pragma unroll
+            for (int p = 0; p < 6; p++) red.push(live ? g[p] : 0.);
+#pragma unroll
+            for (int i = 0; i < NC; i++) {
+                double w[6], wb[6];
+#pragma unroll
+                for (int b = 0; b < 6; b++) w[b] = blk1[blk_index(NB, 27 + 6 * i + b, vv)];
+                times_B(w, wb);
+#pragma unroll
+                for (int b = 0; b < 6; b++) red.push(live ? wb[b] : 0.);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // the relative-pose sums are done before the view's system takes registers
+        }
+#pragma unroll
+        for (int r = 0; r < 6; r++) times_A(V3[r], M[r]);
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                if (q >= p) Vu[tri6(p, q)] = blk0[blk_index(NB, tri6(p, q), vv)] + (Ar[p] * M[0][q] + Ar[3 + p] * M[1][q] + Ar[6 + p] * M[2][q]);
+                if (q >= 3 + p)
+                    Vu[tri6(3 + p, q)] = blk0[blk_index(NB, tri6(3 + p, q), vv)] + (R2[p] * M[3][q] + R2[3 + p] * M[4][q] + R2[6 + p] * M[5][q]);
+                ZL[p][q] = Brr[p] * M[0][q] + Brr[3 + p] * M[1][q] + Brr[6 + p] * M[2][q] + Btr[p] * M[3][q] + Btr[3 + p] * M[4][q] +
+                           Btr[6 + p] * M[5][q];
+                ZL[3 + p][q] = M[3 + p][q];
+            }
+        double g[6];
+        times_A(ge3, g);
+#pragma unroll
+        for (int k = 0; k < 6; k++) y[k] = blk0[blk_index(NB, 21 + k, vv)] + g[k];
+    }
+    double L[21], invd[6];
+    const bool use = chol6(Vu, lambda, L, invd) && live;
+    if (!use) {  // a view that does not count: with a zero factor every forward solve, hence every product, is zero
+#pragma unroll
+        for (int k = 0; k < 21; k++) L[k] = 0.;
+#pragma unroll
+        for (int k = 0; k < 6; k++) invd[k] = 0.;
+    }
+    chol6_fwd(L, invd, y);
+#pragma unroll
+    for (int r = 0; r < 6; r++) chol6_fwd(L, invd, ZL[r]);
+    auto dot = [&](const double p[6], const double q[6]) {
+        double d = 0;
+#pragma unroll
+        for (int b = 0; b < 6; b++) d += p[b] * q[b];
+        return d;
+    };
+    auto load_c0 = [&](int i, double z[6]) {
+#pragma unroll
+        for (int b = 0; b < 6; b++) z[b] = blk0[blk_index(NB, 27 + 6 * i + b, vv)];
+        chol6_fwd(L, invd, z);
+    };
+    {   // pass A
+        double Z0[NC][6];
+#pragma unroll
+        for (int i = 0; i < NC; i++) load_c0(i, Z0[i]);
+#pragma unroll
+        for (int p = 0; p < 6; p++)
+#pragma unroll
+            for (int q = p; q < 6; q++) red.push(dot(ZL[p], ZL[q]));
+#pragma unroll
+        for (int p = 0; p < 6; p++)
+#pragma unroll
+            for (int i = 0; i < NC; i++) red.push(dot(ZL[p], Z0[i]));
+#pragma unroll
+        for (int i = 0; i < NC; i++)
+#pragma unroll
+            for (int j = i; j < NC; j++) red.push(dot(Z0[i], Z0[j]));
+#pragma unroll
+        for (int p = 0; p < 6; p++) red.push(dot(ZL[p], y));
+#pragma unroll
+        for (int i = 0; i < NC; i++) red.push(dot(Z0[i], y));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {   // passes B and C
+        double Z1[NC][6];
+#pragma unroll
+        for (int i = 0; i < NC; i++) {
+            double w[6];
+#pragma unroll
+            for (int b = 0; b < 6; b++) w[b] = blk1[blk_index(NB, 27 + 6 * i + b, vv)];
+            times_A(w, Z1[i]);
+            chol6_fwd(L, invd, Z1[i]);
+        }
+#pragma unroll
+        for (int p = 0; p < 6; p++)
+#pragma unroll
+            for (int i = 0; i < NC; i++) red.push(dot(ZL[p], Z1[i]));
+#pragma unroll
+        for (int i = 0; i < NC; i++)
+#pragma unroll
+            for (int j = i; j < NC; j++) red.push(dot(Z1[i], Z1[j]));
+#pragma unroll
+        for (int i = 0; i < NC; i++) red.push(dot(Z1[i], y));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NC; i++) {
+            double z[6];
+            load_c0(i, z);
+#pragma unroll
+            for (int j = 0; j < NC; j++) red.push(dot(z, Z1[j]));
+        }
+    }
+    red.flush();
+}
+
 template <int NC0, int NC1>
 __global__ __launch_bounds__(64) void k_stereo_backsub(const double* blk0, const double* blk1, const double* cmp,
                                                        StereoLR lr, int npad, int nviews, double lambda, StereoDelta d,
-                                                       const double* pose_prev, double* pose_cur, double* part, double* pc) {
+                                                       const double* pose_prev, double* pose_cur, double* part, double* pc,
+                                                       StereoLR lr_new, double* pose3, double* pc3) {
     int v = blockIdx.x * 64 + threadIdx.x;
     bool live = v < nviews;
     int vv = live ? v : nviews - 1;
@@ -384,6 +821,25 @@ __global__ __launch_bounds__(64) void k_stereo_backsub(const double* blk0, const
         part[2 * blockIdx.x] = dn;
         part[2 * blockIdx.x + 1] = pn;
     }
+    if (pose3) {  // camera 1's trial pose (k_compose without the derivatives): (r3,t3) = lr_new o (r1,t1)
+        double r1[3] = {pnew[0], pnew[1], pnew[2]}, r2[3] = {lr_new.v[0], lr_new.v[1], lr_new.v[2]};
+        double R1[9], R2n[9], R3[9], p3[6];
+        rodrigues<false>(r1, R1, nullptr);
+        rodrigues<false>(r2, R2n, nullptr);
+        mul33(R2n, R1, R3);
+        M2V m = rodrigues_m2v(R3);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            p3[i] = m.r[i];
+            p3[3 + i] = R2n[i * 3] * pnew[3] + R2n[i * 3 + 1] * pnew[4] + R2n[i * 3 + 2] * pnew[5] + lr_new.v[3 + i];
+        }
+        wave_store_rows<6>(p3, sm, pose3 + 6 * (size_t)v0, nlive);
+        if (pc3) {
+            double rec[16];
+            store_pose_const(p3, rec);
+            wave_store_rows<16>(rec, sm, pc3 + 16 * (size_t)v0, nlive);
+        }
+    }
 }
 
 }  // namespace
@@ -406,9 +862,10 @@ static void schur_t(dim3 grid, hipStream_t st, const double* blk0, const double*
 template <int NC>
 static void backsub_t(dim3 grid, hipStream_t st, const double* blk0, const double* blk1, const double* cmp,
                       const StereoLR& lr, int npad, int nviews, double lambda, const StereoDelta& d,
-                      const double* pose_prev, double* pose_cur, double* part, double* pc) {
+                      const double* pose_prev, double* pose_cur, double* part, double* pc, const StereoLR& lr_new, double* pose3,
+                      double* pc3) {
     hipLaunchKernelGGL((k_stereo_backsub<NC, NC>), grid, dim3(64), 0, st, blk0, blk1, cmp, lr, npad, nviews, lambda, d,
-                       pose_prev, pose_cur, part, pc);
+                       pose_prev, pose_cur, part, pc, lr_new, pose3, pc3);
 }
 
 // column counts of the built-in column sets (kernels.hip)
@@ -436,11 +893,132 @@ bool launch_stereo_schur(int nc, const double* blk0, const double* blk1, const d
     return true;
 }
 
+int stereo_sums_rows(int nviews) {
+    static const int cap = [] {
+        const char* e = std::getenv("CCALIB_SUMS_GRID");
+        int v = e ? std::atoi(e) : 0;
+        return v > 0 ? v : 2048;
+    }();
+    return std::max(1, std::min((nviews + 15) / 16, cap));
+}
+
+int stereo_sums_table(int nc, short* out) {
+    if (nc != 6 && nc != 8 && nc != 9 && nc != 11 && nc != 12) return 0;
+    const int kc = 6 + 2 * nc, ns = quad_nslot(nc), sc = quad_sc(nc), nlr = quad_nlr(nc), n = nlr + quad_ngram(nc);
+    if (!out) return 4 * n;
+    auto tri = [kc](int i, int j) { return i * kc - i * (i - 1) / 2 + (j - i); };
+    for (int i = 0; i < 4 * n; i++) out[i] = -1;
+    for (int a = 0; a < 4; a++) {
+        // relative-pose values: slot ls (0, 1: relative-pose slots; 2+i: camera-1 slot i), component j
+        for (int ls = 0; ls < 2 + sc; ls++)
+            for (int j = 0; j < 6; j++) {
+                int e = -1;
+                if (ls < 2) {
+                    const int r = 4 * ls + a;
+                    if (r < 6 && j >= r) e = r * 6 - r * (r - 1) / 2 + (j - r);
+                    if (r == 6) e = 21 + j;
+                } else if (4 * (ls - 2) + a < nc)
+                    e = 27 + 6 * (4 * (ls - 2) + a) + j;
+                if (e >= 0) out[4 * (6 * ls + j) + a] = (short)(-2 - e);
+            }
+        for (int t = 0; t < 3; t++)
+            for (int s1 = 0; s1 < ns; s1++)
+                for (int s2 = (t == 1 ? 0 : s1); s2 < ns; s2++) {
+                    const int r1 = quad_row(nc, s1, a), r2 = quad_row(nc, s2, (a + t) & 3);
+                    if (r1 < 0 || r2 < 0 || (r1 == kc && r2 == kc)) continue;
+                    if (t == 2 && s1 == s2 && a >= 2) continue;  // the lane two places on takes the same product
+                    const int lo = std::min(r1, r2), hi = std::max(r1, r2);
+                    const int e = hi == kc ? kc * (kc + 1) / 2 + lo : tri(lo, hi);
+                    out[4 * (nlr + quad_gram_index(nc, t, s1, s2)) + a] = (short)e;
+                }
+    }
+    // every sum must be produced exactly once
+    std::vector<int> hits_s(kc * (kc + 1) / 2 + kc, 0), hits_l(27 + 6 * nc, 0);
+    for (int i = 0; i < 4 * n; i++) {
+        if (out[i] >= 0) hits_s[out[i]]++;
+        if (out[i] <= -2) hits_l[-2 - out[i]]++;
+    }
+    for (int h : hits_s)
+        if (h != 1) return 0;
+    for (int h : hits_l)
+        if (h != 1) return 0;
+    return 4 * n;
+}
+
+// destinations of k_stereo_view_sums' products, in the order it pushes them: first the relative-pose sums
+// (27 + 6 nc entries, as -2 - index), then the Schur sums (index into the packed upper triangle + right-hand side)
+int stereo_view_table(int nc, short* out) {
+    const int kc = 6 + 2 * nc, nlr = 27 + 6 * nc, nsum = kc * (kc + 1) / 2 + kc;
+    if (!out) return nlr + nsum;
+    auto tri = [kc](int i, int j) { return i * kc - i * (i - 1) / 2 + (j - i); };
+    const int rhs = kc * (kc + 1) / 2;
+    int n = 0;
+    for (int i = 0; i < nlr; i++) out[n++] = (short)(-2 - i);
+    for (int p = 0; p < 6; p++)
+        for (int q = p; q < 6; q++) out[n++] = (short)tri(p, q);
+    for (int p = 0; p < 6; p++)
+        for (int i = 0; i < nc; i++) out[n++] = (short)tri(p, 6 + i);
+    for (int i = 0; i < nc; i++)
+        for (int j = i; j < nc; j++) out[n++] = (short)tri(6 + i, 6 + j);
+    for (int p = 0; p < 6 + nc; p++) out[n++] = (short)(rhs + p);
+    for (int p = 0; p < 6; p++)
+        for (int i = 0; i < nc; i++) out[n++] = (short)tri(p, 6 + nc + i);
+    for (int i = 0; i < nc; i++)
+        for (int j = i; j < nc; j++) out[n++] = (short)tri(6 + nc + i, 6 + nc + j);
+    for (int i = 0; i < nc; i++) out[n++] = (short)(rhs + 6 + nc + i);
+    for (int i = 0; i < nc; i++)
+        for (int j = 0; j < nc; j++) out[n++] = (short)tri(6 + i, 6 + nc + j);
+    std::vector<int> hits(nsum, 0);
+    for (int i = nlr; i < n; i++) hits[out[i]]++;
+    for (int h : hits)
+        if (h != 1) return 0;
+    return n == nlr + nsum ? n : 0;
+}
+
+template <int NC>
+static void view_sums_t(dim3 grid, hipStream_t st, const double* blk0, const double* blk1, const double* cmp, const StereoLR& lr,
+                        int npad, int nviews, double lambda, const short* dst, double* part, double* part_lr) {
+    if (part_lr)
+        hipLaunchKernelGGL((k_stereo_view_sums<NC, true>), grid, dim3(64), 0, st, blk0, blk1, cmp, lr, npad, nviews, lambda, dst,
+                           part, part_lr);
+    else
+        hipLaunchKernelGGL((k_stereo_view_sums<NC, false>), grid, dim3(64), 0, st, blk0, blk1, cmp, lr, npad, nviews, lambda, dst,
+                           part, part_lr);
+}
+
+bool launch_stereo_view_sums(int nc, const double* blk0, const double* blk1, const double* cmp, const StereoLR& lr, int npad,
+                             int nviews, double lambda, const short* dst, double* part, double* part_lr, hipStream_t st) {
+    dim3 grid((nviews + 63) / 64);
+    CCALIB_FOR_NC(nc, view_sums_t, grid, st, blk0, blk1, cmp, lr, npad, nviews, lambda, dst, part, part_lr);
+    return true;
+}
+
+template <int NC>
+static void sums_t(dim3 grid, hipStream_t st, const double* blk0, const double* blk1, const double* cmp, const StereoLR& lr,
+                   int npad, int nviews, int ngroups, double lambda, const short* tab, double* part, double* part_lr) {
+    if (part_lr)
+        hipLaunchKernelGGL((k_stereo_sums<NC, true>), grid, dim3(64), 0, st, blk0, blk1, cmp, lr, npad, nviews, ngroups, lambda,
+                           tab, part, part_lr);
+    else
+        hipLaunchKernelGGL((k_stereo_sums<NC, false>), grid, dim3(64), 0, st, blk0, blk1, cmp, lr, npad, nviews, ngroups, lambda,
+                           tab, part, part_lr);
+}
+
+bool launch_stereo_sums(int nc, const double* blk0, const double* blk1, const double* cmp, const StereoLR& lr, int npad,
+                        int nviews, double lambda, const short* tab, int rows, double* part, double* part_lr, hipStream_t st) {
+    dim3 grid(rows);
+    const int ngroups = (nviews + 15) / 16;
+    CCALIB_FOR_NC(nc, sums_t, grid, st, blk0, blk1, cmp, lr, npad, nviews, ngroups, lambda, tab, part, part_lr);
+    return true;
+}
+
 bool launch_stereo_backsub(int nc, const double* blk0, const double* blk1, const double* cmp, const StereoLR& lr,
                            int npad, int nviews, double lambda, const StereoDelta& d, const double* pose_prev,
-                           double* pose_cur, double* part, double* pc, hipStream_t st) {
+                           double* pose_cur, double* part, double* pc, const StereoLR& lr_new, double* pose3, double* pc3,
+                           hipStream_t st) {
     dim3 grid((nviews + 63) / 64);
-    CCALIB_FOR_NC(nc, backsub_t, grid, st, blk0, blk1, cmp, lr, npad, nviews, lambda, d, pose_prev, pose_cur, part, pc);
+    CCALIB_FOR_NC(nc, backsub_t, grid, st, blk0, blk1, cmp, lr, npad, nviews, lambda, d, pose_prev, pose_cur, part, pc, lr_new,
+                  pose3, pc3);
     return true;
 }
 
