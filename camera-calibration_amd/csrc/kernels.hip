@@ -784,55 +784,63 @@ __global__ __launch_bounds__(64) void k_backsub(const double* blk, int npad, int
 }
 
 // Column sums of several partial-result tables in one launch.  Workgroup b reduces one column of
-// one table: out[seg.out_ofs + k] = sum over rows of seg.part[row * seg.n + k], as a fixed-order tree.
-// `out` may be host memory the device can write; the last workgroup to finish then stores `seq` to
-// *flag (also host memory), which a polling host thread takes as "all sums have landed".
-__global__ __launch_bounds__(kBlock) void k_colsum(ColsumArgs a, double* out, unsigned* counter,
+// one table: out[seg.out_ofs + k] = sum over rows of seg.part[row * seg.n + k], as a fixed-order tree; `out` is
+// device memory.  With `flag` set, the last workgroup to finish copies out[0..n_out) to host_out (pinned host
+// memory) in one piece and then stores `seq` to *flag (also pinned), which a polling host thread takes as "all sums
+// have landed": one burst over the bus instead of one 8-byte write and one system-wide fence per workgroup.
+__global__ __launch_bounds__(kBlock) void k_colsum(ColsumArgs a, double* out, unsigned* counter, double* host_out, int n_out,
                                                    volatile unsigned long long* flag, unsigned long long seq,
                                                    const LmCtrl* __restrict__ ctrl, LmStepArgs st, int has_step) {
-    __shared__ double sm[kBlock];
+    __shared__ double sm[kWaves];
     __shared__ int is_last;
     if (ctrl && !ctrl->go) return;
     int k = blockIdx.x, sidx = 0;
     while (sidx + 1 < a.nseg && k >= a.seg[sidx].n) k -= a.seg[sidx].n, sidx++;
     const ColsumSeg sg = a.seg[sidx];
-    // four loads in flight per thread (the rows are a cache line or more apart): summed in a fixed order
-    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    int r = threadIdx.x;
-    for (; r + 3 * kBlock < sg.nrows; r += 4 * kBlock) {
-        s0 += sg.part[(size_t)r * sg.n + k];
-        s1 += sg.part[(size_t)(r + kBlock) * sg.n + k];
-        s2 += sg.part[(size_t)(r + 2 * kBlock) * sg.n + k];
-        s3 += sg.part[(size_t)(r + 3 * kBlock) * sg.n + k];
+    // eight loads in flight per thread (the rows are a cache line or more apart, so every load is a round trip of
+    // its own, and with a few hundred workgroups in all nothing else hides it): summed in a fixed order
+    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int r0 = threadIdx.x; r0 < sg.nrows; r0 += 8 * kBlock) {
+        double t[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int r = r0 + j * kBlock;
+            t[j] = r < sg.nrows ? sg.part[(size_t)r * sg.n + k] : 0.;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) s[j] += t[j];
     }
-    for (; r < sg.nrows; r += kBlock) s0 += sg.part[(size_t)r * sg.n + k];
-    sm[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    const double ws = wave_sum(((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7])));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = ws;
     __syncthreads();
-    for (int h = kBlock / 2; h > 0; h >>= 1) {
-        if ((int)threadIdx.x < h) sm[threadIdx.x] += sm[threadIdx.x + h];
-        __syncthreads();
-    }
     if (threadIdx.x == 0) {
-        out[sg.out_ofs + k] = sm[0];
+        double tot = sm[0];
+        for (int ww = 1; ww < kWaves; ww++) tot += sm[ww];
+        out[sg.out_ofs + k] = tot;
         is_last = 0;
         if (flag || has_step) {
-            __threadfence_system();
+            __threadfence();
             if (atomicAdd(counter, 1u) == gridDim.x - 1) {
                 *counter = 0;
-                __threadfence_system();
-                if (has_step)
-                    is_last = 1;
-                else
-                    *flag = seq;
+                __threadfence();
+                is_last = 1;
             }
         }
     }
+    if (!flag && !has_step) return;
+    __syncthreads();
+    if (!is_last) return;
     if (has_step) {
         // The workgroup that finishes last holds every sum of the pass: its first wavefront publishes them and
         // predicts the host's next step (lm_step_body.hpp) without another kernel boundary in between.
         __shared__ LmStepLds w;
+        if (threadIdx.x < 64) lm_step_body(st, w, threadIdx.x);
+    } else {
+        const volatile double* src = out;  // written by other workgroups of this launch
+        for (int i = threadIdx.x; i < n_out; i += kBlock) host_out[i] = src[i];
+        __threadfence_system();
         __syncthreads();
-        if (is_last && threadIdx.x < 64) lm_step_body(st, w, threadIdx.x);
+        if (threadIdx.x == 0) *flag = seq;
     }
 }
 
@@ -978,14 +986,14 @@ void launch_reproj(const PassArgs& a, const CamParams& cp, bool rational, int gr
     });
 }
 
-void launch_colsum(const ColsumArgs& a, double* out, unsigned* counter, unsigned long long* flag, unsigned long long seq,
-                   hipStream_t st, const LmCtrl* ctrl, const LmStepArgs* step) {
+void launch_colsum(const ColsumArgs& a, double* out, unsigned* counter, double* host_out, int n_out, unsigned long long* flag,
+                   unsigned long long seq, hipStream_t st, const LmCtrl* ctrl, const LmStepArgs* step) {
     int total = 0;
     for (int i = 0; i < a.nseg; i++) total += a.seg[i].n;
     static const LmStepArgs none = {};
     if (total > 0)
-        hipLaunchKernelGGL(k_colsum, dim3(total), dim3(kBlock), 0, st, a, out, counter, flag, seq, ctrl, step ? *step : none,
-                           step ? 1 : 0);
+        hipLaunchKernelGGL(k_colsum, dim3(total), dim3(kBlock), 0, st, a, out, counter, host_out, n_out, flag, seq, ctrl,
+                           step ? *step : none, step ? 1 : 0);
 }
 
 void launch_publish(const double* src, int n, double* dst, unsigned long long* flag, unsigned long long seq, hipStream_t st) {

@@ -94,10 +94,11 @@ struct ColsumArgs {
     ColsumSeg seg[kMaxColsumSegs];
     int nseg;
 };
-// With `step`, the workgroup that finishes last also runs the LM step prediction on the sums (which must then go
-// to device memory: step->red == out) and publishes through step->hred / step->flag instead of flag / seq.
-void launch_colsum(const ColsumArgs&, double* out, unsigned* counter, unsigned long long* flag, unsigned long long seq,
-                   hipStream_t, const LmCtrl* ctrl = nullptr, const LmStepArgs* step = nullptr);
+// The sums go to `out` (device memory).  With `flag`, the workgroup that finishes last copies out[0..n_out) to
+// host_out and raises the flag.  With `step`, it instead runs the LM step prediction on the sums (step->red == out)
+// and publishes through step->hred / step->flag.
+void launch_colsum(const ColsumArgs&, double* out, unsigned* counter, double* host_out, int n_out, unsigned long long* flag,
+                   unsigned long long seq, hipStream_t, const LmCtrl* ctrl = nullptr, const LmStepArgs* step = nullptr);
 void launch_publish(const double* src, int n, double* dst, unsigned long long* flag, unsigned long long seq, hipStream_t);
 int pass_block_size();
 // dynamic LDS one workgroup of the per-point kernels needs

@@ -73,7 +73,6 @@ struct ccalib_solver {
     int cur = 0;
     short* d_sums_tab = nullptr;                            // stereo: where the products of the sums kernel go
     short* d_view_tab = nullptr;                            // stereo: the same for the one-lane-per-view kernel
-    bool sums_old = false;
     bool sums_quad = false;                                 // stereo: four lanes per view in the sums kernel
     int sums_rows = 0;                                      // stereo: partial-sum rows (workgroups) of the sums kernel
     double* d_cmp[2] = {nullptr, nullptr};                  // stereo: per-view composition Jacobians (SoA), per buffer
@@ -148,7 +147,8 @@ struct ccalib_solver {
 
     // One iteration run ahead of the host (lm_step.hpp): the kernels of the next trial step are enqueued before the
     // host has seen the sums of the current one and take their parameters from a control block the device writes.
-    bool chain_enabled = true;       // CCALIB_NO_CHAIN=1 turns it off
+    int split_publish = -1;          // CCALIB_SPLIT_PUBLISH=0/1 forces where the sums are published from (-1: by size)
+    bool chain_enabled = false;      // CCALIB_CHAIN=1 turns running ahead of the host on (measured: no gain)
     LmCtrl* d_ctrl = nullptr;        // [2], indexed by the slot of the iteration that reads it
     LmMaps* d_maps = nullptr;
     LmMaps h_maps;
@@ -234,29 +234,41 @@ int queue_colsum(ccalib_solver* s, const double* part, int nrows, int n, int out
 }
 
 // Reduces everything queued in this pass into n sums, over ranks too (if any), and sends them to the pinned
-// buffer of the current slot.  Plain passes: the column-sum kernel writes pinned host memory directly and raises
-// the flag (RCCL runs: sums land in device memory, are all-reduced in-stream and then published).  Jacobian
+// buffer of the current slot.  Plain passes: the last workgroup of the column-sum kernel copies the sums to pinned
+// host memory and raises the flag (RCCL runs: the sums are all-reduced in-stream and then published).  Jacobian
 // passes of a run that may run ahead (`step` given): the sums stay in device memory, and k_lm_step publishes them
 // together with its prediction of the next step.  `ctrl`: control block of a run-ahead iteration (its kernels
 // return at once when the iteration was called off), else null.
 int submit_reduction(ccalib_solver* s, int n, const LmCtrl* ctrl, LmStepArgs* step, Pending* out) {
     const int q = s->slot;
     const unsigned long long seq = ++s->seq;
+    // Publishing from the last workgroup of the column-sum kernel saves a kernel boundary (~3 us) but costs every
+    // workgroup a device-wide fence and an atomic on one counter (~35 ns each, serialised): past a few hundred
+    // columns a publishing kernel of its own is cheaper (499 columns: 25.1 us against 8.9 + 3.9).
+    int ncol = 0;
+    for (int i = 0; i < s->segs.nseg; i++) ncol += s->segs.seg[i].n;
+    const bool split = s->split_publish >= 0 ? s->split_publish != 0 : ncol >= 160;
     if (step) {
         step->red = s->d_red[q], step->n = n, step->hred = s->h_red[q], step->flag = s->h_flag[q], step->seq = seq;
         step->cin = ctrl;
         if (s->comm) {  // the sums pass through the all-reduce first: the step runs as a kernel of its own after it
-            launch_colsum(s->segs, s->d_red[q], s->d_counter, nullptr, 0, s->stream, ctrl);
+            launch_colsum(s->segs, s->d_red[q], s->d_counter, nullptr, 0, nullptr, 0, s->stream, ctrl);
             NCCL_TRY(ncclAllReduce(s->d_red[q], s->d_red[q], n, ncclDouble, ncclSum, s->comm, s->stream));
             launch_lm_step(*step, s->stream);
+        } else if (split) {
+            launch_colsum(s->segs, s->d_red[q], s->d_counter, nullptr, 0, nullptr, 0, s->stream, ctrl);
+            launch_lm_step(*step, s->stream);
         } else  // single GPU: the last workgroup of the column-sum kernel runs it
-            launch_colsum(s->segs, s->d_red[q], s->d_counter, nullptr, 0, s->stream, ctrl, step);
+            launch_colsum(s->segs, s->d_red[q], s->d_counter, nullptr, 0, nullptr, 0, s->stream, ctrl, step);
     } else if (s->comm) {
-        launch_colsum(s->segs, s->d_red[q], s->d_counter, nullptr, 0, s->stream, ctrl);
+        launch_colsum(s->segs, s->d_red[q], s->d_counter, nullptr, 0, nullptr, 0, s->stream, ctrl);
         NCCL_TRY(ncclAllReduce(s->d_red[q], s->d_red[q], n, ncclDouble, ncclSum, s->comm, s->stream));
         launch_publish(s->d_red[q], n, s->h_red[q], s->h_flag[q], seq, s->stream);
+    } else if (split) {
+        launch_colsum(s->segs, s->d_red[q], s->d_counter, nullptr, 0, nullptr, 0, s->stream, ctrl);
+        launch_publish(s->d_red[q], n, s->h_red[q], s->h_flag[q], seq, s->stream);
     } else {
-        launch_colsum(s->segs, s->h_red[q], s->d_counter, s->h_flag[q], seq, s->stream, ctrl);
+        launch_colsum(s->segs, s->d_red[q], s->d_counter, s->h_red[q], n, s->h_flag[q], seq, s->stream, ctrl);
     }
     s->segs.nseg = 0;
     s->part_used = 0;
@@ -385,12 +397,9 @@ int enqueue_schur(ccalib_solver* s, int buf, double lambda, int ofs, const LmCtr
     if (s->sums_quad)
         ok = launch_stereo_sums(s->ops[0]->NC, s->d_blk[0][buf], s->d_blk[1][buf], s->d_cmp[buf], s->lr_jac[buf], s->npad,
                                 s->nviews, lambda, s->d_sums_tab, s->sums_rows, part, part_lr, s->stream);
-    else if (!s->sums_old)
-        ok = launch_stereo_view_sums(s->ops[0]->NC, s->d_blk[0][buf], s->d_blk[1][buf], s->d_cmp[buf], s->lr_jac[buf], s->npad,
-                                     s->nviews, lambda, s->d_view_tab, part, part_lr, s->stream);
     else {
-        ok = launch_stereo_schur(s->ops[0]->NC, s->d_blk[0][buf], s->d_blk[1][buf], s->d_cmp[buf], s->lr_jac[buf], s->npad,
-                                 s->nviews, lambda, part, s->stream);
+        ok = launch_stereo_view_sums(s->ops[0]->NC, s->d_blk[0][buf], s->d_blk[1][buf], s->d_cmp[buf], s->lr_jac[buf], s->npad,
+                                     s->nviews, lambda, s->d_view_tab, part, s->stream);
         if (ok && part_lr)
             ok = launch_stereo_lr_sums(s->ops[1]->NC, s->d_blk[1][buf], s->d_cmp[buf], s->lr_jac[buf], s->npad, s->nviews,
                                        part_lr, s->stream);
@@ -1006,7 +1015,8 @@ int ccalib_solver_create(ccalib_solver** out, int device, int ncams, int nviews,
     HIP_TRY(hipMemset(s->d_ctrl, 0, sizeof(LmCtrl) * 2));
     HIP_TRY(hipMalloc(&s->d_maps, sizeof(LmMaps)));
     std::memset(&s->h_maps, 0, sizeof(LmMaps));
-    if (const char* e = std::getenv("CCALIB_NO_CHAIN")) s->chain_enabled = std::atoi(e) == 0;
+    if (const char* e = std::getenv("CCALIB_CHAIN")) s->chain_enabled = std::atoi(e) != 0;
+    if (const char* e = std::getenv("CCALIB_SPLIT_PUBLISH")) s->split_publish = std::atoi(e) != 0;
     HIP_TRY(hipMalloc(&s->d_counter, sizeof(unsigned)));
     HIP_TRY(hipMemset(s->d_counter, 0, sizeof(unsigned)));
     s->segs.nseg = 0;
@@ -1085,8 +1095,6 @@ int ccalib_solver_set_start(ccalib_solver* s, const double* intr, const unsigned
             if (!stereo_view_table(m->NC, vt.data())) return set_error(CCALIB_ERR_STATE, "stereo sum table is inconsistent");
             if (!s->d_view_tab) HIP_TRY(hipMalloc(&s->d_view_tab, sizeof(short) * stereo_view_table(12, nullptr)));
             HIP_TRY(hipMemcpy(s->d_view_tab, vt.data(), sizeof(short) * vt.size(), hipMemcpyHostToDevice));
-            const char* eo = std::getenv("CCALIB_SUMS_OLD");
-            s->sums_old = eo && std::atoi(eo) != 0;
         }
         // Few views: four lanes per view fill the chip where one lane per view would leave most of it idle.
         // Many views: one lane per view issues a quarter of the instructions.

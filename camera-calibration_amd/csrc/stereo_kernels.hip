@@ -140,8 +140,12 @@ __device__ __forceinline__ void load_cmp(const double* cmp, int npad, int v, con
         c.Brr[k] = cmp[(size_t)(9 + k) * npad + v];
         c.Btr[k] = cmp[(size_t)(18 + k) * npad + v];
     }
-    double r2[3] = {lr.v[0], lr.v[1], lr.v[2]};
-    rodrigues<false>(r2, c.R2, nullptr);
+    double r2[3] = {lr.v[0], lr.v[1], lr.v[2]}, Rv[9];
+    rodrigues<false>(r2, Rv, nullptr);
+#pragma unroll
+    for (int k = 0; k < 9; k++)  // the same in every lane: kept in scalar registers
+        c.R2[k] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(Rv[k])),
+                                   __builtin_amdgcn_readfirstlane(__double2loint(Rv[k])));
 }
 // row-vector (6) times A or B
 __device__ __forceinline__ void row_times_A(const Cmp& c, const double w[6], double o[6]) {
@@ -261,68 +265,6 @@ __device__ __forceinline__ void assemble_view(const double* blk0, const double* 
         s.ge[3 + a] =
             blk0[blk_index((27 + 6 * NC0), 24 + a, vv)] + c.R2[a] * ge3[3] + c.R2[3 + a] * ge3[4] + c.R2[6 + a] * ge3[5];
     }
-}
-
-template <int NC0, int NC1>
-__global__ __launch_bounds__(64) void k_stereo_schur(const double* blk0, const double* blk1, const double* cmp,
-                                                     StereoLR lr, int npad, int nviews, double lambda, double* part) {
-    constexpr int KC = 6 + NC0 + NC1;
-    constexpr int NS = KC * (KC + 1) / 2 + KC;
-    int v = blockIdx.x * 64 + threadIdx.x;
-    bool live = v < nviews;
-    int vv = live ? v : nviews - 1;
-    Cmp c;
-    load_cmp(cmp, npad, vv, lr, c);
-    ViewSys s;
-    assemble_view<NC0, NC1>(blk0, blk1, npad, vv, c, s);
-    double L[21], invd[6], y[6], Z[KC][6];
-    bool ok = chol6(s.Vu, lambda, L, invd) && live;
-#pragma unroll
-    for (int k = 0; k < 6; k++) y[k] = s.ge[k];
-    chol6_fwd(L, invd, y);
-    {
-        double WLR[6][6];
-        Bt_times(c, s.M, WLR);  // B^T V3 A
-#pragma unroll
-        for (int a = 0; a < 6; a++) {
-#pragma unroll
-            for (int b = 0; b < 6; b++) Z[a][b] = WLR[a][b];
-            chol6_fwd(L, invd, Z[a]);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < NC0; i++) {
-#pragma unroll
-        for (int b = 0; b < 6; b++) Z[6 + i][b] = blk0[blk_index((27 + 6 * NC0), 27 + 6 * i + b, vv)];
-        chol6_fwd(L, invd, Z[6 + i]);
-    }
-#pragma unroll
-    for (int i = 0; i < NC1; i++) {
-        double w[6];
-#pragma unroll
-        for (int b = 0; b < 6; b++) w[b] = blk1[blk_index((27 + 6 * NC1), 27 + 6 * i + b, vv)];
-        row_times_A(c, w, Z[6 + NC0 + i]);
-        chol6_fwd(L, invd, Z[6 + NC0 + i]);
-    }
-    __shared__ double sm[32 * 65];
-    LaneReducer red(sm, part + (size_t)blockIdx.x * NS);
-#pragma unroll
-    for (int i = 0; i < KC; i++)
-#pragma unroll
-        for (int j = i; j < KC; j++) {
-            double d = 0;
-#pragma unroll
-            for (int b = 0; b < 6; b++) d += Z[i][b] * Z[j][b];
-            red.push(ok ? d : 0.);
-        }
-#pragma unroll
-    for (int i = 0; i < KC; i++) {
-        double d = 0;
-#pragma unroll
-        for (int b = 0; b < 6; b++) d += Z[i][b] * y[b];
-        red.push(ok ? d : 0.);
-    }
-    red.flush();
 }
 
 // ---- Schur sums and relative-pose sums, four lanes per view ----------------------------------------
@@ -547,19 +489,21 @@ __global__ __launch_bounds__(64) void k_stereo_sums(const double* __restrict__ b
     }
 }
 
-// ---- Schur sums and relative-pose sums, one lane per view, in three passes over the Gram matrix ----------
+// ---- Schur sums, one lane per view, in three passes over the Gram matrix ---------------------------------
 // Holding all of Z = W L^-T (kc x 6 per view) at once takes more registers than two wavefronts per SIMD leave, and
 // with one wavefront per SIMD nothing hides the latency of the FP64 chains.  So Z is held a part at a time:
 //   pass A: relative-pose rows and camera-0 rows     -> blocks (LR,LR) (LR,c0) (c0,c0) and their right-hand sides
 //   pass B: camera-1 rows replace camera-0 rows      -> blocks (LR,c1) (c1,c1) and theirs
 //   pass C: camera-0 rows again, one at a time       -> block (c0,c1)
 // Products leave in that order; `dst` (stereo_view_table) says where each belongs in the packed sums.
+// (The relative-pose sums stay in k_stereo_lr_sums: taken along here they cost 15-19 us against 12.5 us there,
+// because at two wavefronts per SIMD this kernel's arithmetic is not hidden behind its memory traffic.)
 struct TabReducer {  // LaneReducer with all 64 lanes adding and a destination table
     double* sm;
     const short* dst;
-    double *out0, *out1;
+    double* out;
     int k = 0, base = 0;
-    __device__ __forceinline__ TabReducer(double* sm_, const short* dst_, double* o0, double* o1) : sm(sm_), dst(dst_), out0(o0), out1(o1) {}
+    __device__ __forceinline__ TabReducer(double* sm_, const short* dst_, double* o) : sm(sm_), dst(dst_), out(o) {}
     __device__ __forceinline__ void push(double v) {
         sm[k * 65 + (threadIdx.x & 63)] = v;
         if (++k == 32) flush();
@@ -574,29 +518,23 @@ struct TabReducer {  // LaneReducer with all 64 lanes adding and a destination t
         for (int j = 0; j < 32; j += 4) s0 += row[j], s1 += row[j + 1], s2 += row[j + 2], s3 += row[j + 3];
         double s = (s0 + s1) + (s2 + s3);
         s += __shfl_xor(s, 32);
-        if (lane < k) {
-            const int e = dst[base + lane];
-            if (e >= 0)
-                out0[e] = s;
-            else
-                out1[-2 - e] = s;
-        }
+        if (lane < k) out[dst[base + lane]] = s;
         __builtin_amdgcn_wave_barrier();
         base += k;
         k = 0;
     }
 };
 
-template <int NC, bool WITH_LR>
+template <int NC>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_stereo_view_sums(
     const double* __restrict__ blk0, const double* __restrict__ blk1, const double* __restrict__ cmp, StereoLR lr, int npad,
-    int nviews, double lambda, const short* __restrict__ dst, double* __restrict__ part, double* __restrict__ part_lr) {
-    constexpr int NB = 27 + 6 * NC, KC = 6 + 2 * NC, NSUM = KC * (KC + 1) / 2 + KC, NOUT = 27 + 6 * NC;
+    int nviews, double lambda, const short* __restrict__ dst, double* __restrict__ part) {
+    constexpr int NB = 27 + 6 * NC, KC = 6 + 2 * NC, NSUM = KC * (KC + 1) / 2 + KC;
     const int v = blockIdx.x * 64 + threadIdx.x;
     const bool live = v < nviews;
     const int vv = live ? v : nviews - 1;
     __shared__ double sm[32 * 65];
-    TabReducer red(sm, dst + (WITH_LR ? 0 : NOUT), part + (size_t)blockIdx.x * NSUM, part_lr + (size_t)blockIdx.x * NOUT);
+    TabReducer red(sm, dst, part + (size_t)blockIdx.x * NSUM);
     double Ar[9], R2[9];
     {
         double r2[3] = {lr.v[0], lr.v[1], lr.v[2]}, Rv[9];
@@ -616,6 +554,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
     };
     double ZL[6][6], Vu[21], y[6];
+#pragma unroll
+    for (int k = 0; k < 21; k++) Vu[k] = blk0[blk_index(NB, k, vv)];
+#pragma unroll
+    for (int k = 0; k < 6; k++) y[k] = blk0[blk_index(NB, 21 + k, vv)];
     {
         double V3[6][6], ge3[6], M[6][6], Brr[9], Btr[9];
         {
@@ -628,50 +570,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         for (int k = 0; k < 6; k++) ge3[k] = blk1[blk_index(NB, 21 + k, vv)];
 #pragma unroll
         for (int k = 0; k < 9; k++) Brr[k] = cmp[(size_t)(9 + k) * npad + vv], Btr[k] = cmp[(size_t)(18 + k) * npad + vv];
-        auto times_B = [&](const double w[6], double o[6]) {
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                o[j] = w[0] * Brr[j] + w[1] * Brr[3 + j] + w[2] * Brr[6 + j] + w[3] * Btr[j] + w[4] * Btr[3 + j] + w[5] * Btr[6 + j];
-                o[3 + j] = w[3 + j];
-            }
-        };
-        if constexpr (WITH_LR) {  // B^T V3 B (upper), B^T ge3, W3 B
-            double N[6][6];
-#pragma unroll
-            for (int r = 0; r < 6; r++) times_B(V3[r], N[r]);
-#pragma unroll
-            for (int p = 0; p < 6; p++)
-#pragma unroll
-                for (int q = p; q < 6; q++) {
-                    double d = p < 3 ? Brr[p] * N[0][q] + Brr[3 + p] * N[1][q] + Brr[6 + p] * N[2][q] + Btr[p] * N[3][q] +
-                                           Btr[3 + p] * N[4][q] + Btr[6 + p] * N[5][q]
-                                     : N[p][q];
-                    red.push(live ? d : 0.);
-                }
-            double g[6];
-            times_B(ge3, g);
-#pragma unroll
-            for (int p = 0; p < 6; p++) red.push(live ? g[p] : 0.);
-#pragma unroll
-            for (int i = 0; i < NC; i++) {
-                double w[6], wb[6];
-#pragma unroll
-                for (int b = 0; b < 6; b++) w[b] = blk1[blk_index(NB, 27 + 6 * i + b, vv)];
-                times_B(w, wb);
-#pragma unroll
-                for (int b = 0; b < 6; b++) red.push(live ? wb[b] : 0.);
-            }
-            __builtin_amdgcn_sched_barrier(0);  // the relative-pose sums are done before the view's system takes registers
-        }
 #pragma unroll
         for (int r = 0; r < 6; r++) times_A(V3[r], M[r]);
 #pragma unroll
         for (int p = 0; p < 3; p++)
 #pragma unroll
             for (int q = 0; q < 6; q++) {
-                if (q >= p) Vu[tri6(p, q)] = blk0[blk_index(NB, tri6(p, q), vv)] + (Ar[p] * M[0][q] + Ar[3 + p] * M[1][q] + Ar[6 + p] * M[2][q]);
-                if (q >= 3 + p)
-                    Vu[tri6(3 + p, q)] = blk0[blk_index(NB, tri6(3 + p, q), vv)] + (R2[p] * M[3][q] + R2[3 + p] * M[4][q] + R2[6 + p] * M[5][q]);
+                if (q >= p) Vu[tri6(p, q)] += Ar[p] * M[0][q] + Ar[3 + p] * M[1][q] + Ar[6 + p] * M[2][q];
+                if (q >= 3 + p) Vu[tri6(3 + p, q)] += R2[p] * M[3][q] + R2[3 + p] * M[4][q] + R2[6 + p] * M[5][q];
                 ZL[p][q] = Brr[p] * M[0][q] + Brr[3 + p] * M[1][q] + Brr[6 + p] * M[2][q] + Btr[p] * M[3][q] + Btr[3 + p] * M[4][q] +
                            Btr[6 + p] * M[5][q];
                 ZL[3 + p][q] = M[3 + p][q];
@@ -679,7 +585,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         double g[6];
         times_A(ge3, g);
 #pragma unroll
-        for (int k = 0; k < 6; k++) y[k] = blk0[blk_index(NB, 21 + k, vv)] + g[k];
+        for (int k = 0; k < 6; k++) y[k] += g[k];
     }
     double L[21], invd[6];
     const bool use = chol6(Vu, lambda, L, invd) && live;
@@ -855,11 +761,6 @@ static void lr_sums_t(dim3 grid, hipStream_t st, const double* blk1, const doubl
     hipLaunchKernelGGL(k_stereo_lr_sums<NC>, grid, dim3(64), 0, st, blk1, cmp, lr, npad, nviews, part);
 }
 template <int NC>
-static void schur_t(dim3 grid, hipStream_t st, const double* blk0, const double* blk1, const double* cmp,
-                    const StereoLR& lr, int npad, int nviews, double lambda, double* part) {
-    hipLaunchKernelGGL((k_stereo_schur<NC, NC>), grid, dim3(64), 0, st, blk0, blk1, cmp, lr, npad, nviews, lambda, part);
-}
-template <int NC>
 static void backsub_t(dim3 grid, hipStream_t st, const double* blk0, const double* blk1, const double* cmp,
                       const StereoLR& lr, int npad, int nviews, double lambda, const StereoDelta& d,
                       const double* pose_prev, double* pose_cur, double* part, double* pc, const StereoLR& lr_new, double* pose3,
@@ -883,13 +784,6 @@ bool launch_stereo_lr_sums(int nc, const double* blk1, const double* cmp, const 
                            double* part, hipStream_t st) {
     dim3 grid((nviews + 63) / 64);
     CCALIB_FOR_NC(nc, lr_sums_t, grid, st, blk1, cmp, lr, npad, nviews, part);
-    return true;
-}
-
-bool launch_stereo_schur(int nc, const double* blk0, const double* blk1, const double* cmp, const StereoLR& lr, int npad,
-                         int nviews, double lambda, double* part, hipStream_t st) {
-    dim3 grid((nviews + 63) / 64);
-    CCALIB_FOR_NC(nc, schur_t, grid, st, blk0, blk1, cmp, lr, npad, nviews, lambda, part);
     return true;
 }
 
@@ -945,15 +839,14 @@ int stereo_sums_table(int nc, short* out) {
     return 4 * n;
 }
 
-// destinations of k_stereo_view_sums' products, in the order it pushes them: first the relative-pose sums
-// (27 + 6 nc entries, as -2 - index), then the Schur sums (index into the packed upper triangle + right-hand side)
+// destinations of k_stereo_view_sums' products, in the order it pushes them (index into the packed upper triangle
+// + right-hand side)
 int stereo_view_table(int nc, short* out) {
-    const int kc = 6 + 2 * nc, nlr = 27 + 6 * nc, nsum = kc * (kc + 1) / 2 + kc;
-    if (!out) return nlr + nsum;
+    const int kc = 6 + 2 * nc, nsum = kc * (kc + 1) / 2 + kc;
+    if (!out) return nsum;
     auto tri = [kc](int i, int j) { return i * kc - i * (i - 1) / 2 + (j - i); };
     const int rhs = kc * (kc + 1) / 2;
     int n = 0;
-    for (int i = 0; i < nlr; i++) out[n++] = (short)(-2 - i);
     for (int p = 0; p < 6; p++)
         for (int q = p; q < 6; q++) out[n++] = (short)tri(p, q);
     for (int p = 0; p < 6; p++)
@@ -969,27 +862,22 @@ int stereo_view_table(int nc, short* out) {
     for (int i = 0; i < nc; i++)
         for (int j = 0; j < nc; j++) out[n++] = (short)tri(6 + i, 6 + nc + j);
     std::vector<int> hits(nsum, 0);
-    for (int i = nlr; i < n; i++) hits[out[i]]++;
+    for (int i = 0; i < n; i++) hits[out[i]]++;
     for (int h : hits)
         if (h != 1) return 0;
-    return n == nlr + nsum ? n : 0;
+    return n == nsum ? n : 0;
 }
 
 template <int NC>
 static void view_sums_t(dim3 grid, hipStream_t st, const double* blk0, const double* blk1, const double* cmp, const StereoLR& lr,
-                        int npad, int nviews, double lambda, const short* dst, double* part, double* part_lr) {
-    if (part_lr)
-        hipLaunchKernelGGL((k_stereo_view_sums<NC, true>), grid, dim3(64), 0, st, blk0, blk1, cmp, lr, npad, nviews, lambda, dst,
-                           part, part_lr);
-    else
-        hipLaunchKernelGGL((k_stereo_view_sums<NC, false>), grid, dim3(64), 0, st, blk0, blk1, cmp, lr, npad, nviews, lambda, dst,
-                           part, part_lr);
+                        int npad, int nviews, double lambda, const short* dst, double* part) {
+    hipLaunchKernelGGL((k_stereo_view_sums<NC>), grid, dim3(64), 0, st, blk0, blk1, cmp, lr, npad, nviews, lambda, dst, part);
 }
 
 bool launch_stereo_view_sums(int nc, const double* blk0, const double* blk1, const double* cmp, const StereoLR& lr, int npad,
-                             int nviews, double lambda, const short* dst, double* part, double* part_lr, hipStream_t st) {
+                             int nviews, double lambda, const short* dst, double* part, hipStream_t st) {
     dim3 grid((nviews + 63) / 64);
-    CCALIB_FOR_NC(nc, view_sums_t, grid, st, blk0, blk1, cmp, lr, npad, nviews, lambda, dst, part, part_lr);
+    CCALIB_FOR_NC(nc, view_sums_t, grid, st, blk0, blk1, cmp, lr, npad, nviews, lambda, dst, part);
     return true;
 }
 

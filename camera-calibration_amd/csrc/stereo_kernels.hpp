@@ -49,23 +49,20 @@ void launch_compose(const double* pose1, const StereoLR& lr, int nviews, int npa
 // B^T V3 B (21, upper), B^T ge3 (6), W3 B (nc x 6).
 bool launch_stereo_lr_sums(int nc, const double* blk1, const double* cmp, const StereoLR& lr, int npad, int nviews,
                            double* part, hipStream_t st);
-// Per 64-view workgroup: upper triangle of sum W V'^-1 W^T and sum W V'^-1 ge over the columns
-// [om_LR T_LR | camera 0 | camera 1].
-bool launch_stereo_schur(int nc, const double* blk0, const double* blk1, const double* cmp, const StereoLR& lr, int npad,
-                         int nviews, double lambda, double* part, hipStream_t st);
 // One pass over the blocks of a Jacobian pass, four lanes per view: the Schur sums for `lambda` (layout as
-// launch_stereo_schur) and, with part_lr != null, the relative-pose sums (layout as launch_stereo_lr_sums), one row
+// launch_stereo_view_sums) and, with part_lr != null, the relative-pose sums (layout as launch_stereo_lr_sums), one row
 // of partial sums per workgroup; `rows` workgroups (stereo_sums_rows()).  `tab` = the device copy of
 // stereo_sums_table(nc).
 int stereo_sums_rows(int nviews);
 int stereo_sums_table(int nc, short* out);  // fills out (when not null), returns the entry count; 0: nc not built in
 bool launch_stereo_sums(int nc, const double* blk0, const double* blk1, const double* cmp, const StereoLR& lr, int npad,
                         int nviews, double lambda, const short* tab, int rows, double* part, double* part_lr, hipStream_t st);
-// The same sums with one lane per view and one row of partial sums per 64 views; `dst` = the device copy of
-// stereo_view_table(nc).
+// The Schur sums with one lane per view and one row of partial sums per 64 views: upper triangle of
+// sum W V'^-1 W^T and sum W V'^-1 ge over the columns [om_LR T_LR | camera 0 | camera 1]; `dst` = the device copy
+// of stereo_view_table(nc).
 int stereo_view_table(int nc, short* out);
 bool launch_stereo_view_sums(int nc, const double* blk0, const double* blk1, const double* cmp, const StereoLR& lr, int npad,
-                             int nviews, double lambda, const short* dst, double* part, double* part_lr, hipStream_t st);
+                             int nviews, double lambda, const short* dst, double* part, hipStream_t st);
 bool launch_stereo_backsub(int nc, const double* blk0, const double* blk1, const double* cmp, const StereoLR& lr,
                            int npad, int nviews, double lambda, const StereoDelta& d, const double* pose_prev,
                            double* pose_cur, double* part, double* pc,  // pc: trial poses as records, or null

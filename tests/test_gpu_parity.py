@@ -432,8 +432,8 @@ def test_running_ahead_of_the_host_changes_nothing(pkg, synth, monkeypatch):
     ms = synth.make_views(obj, 30_011, 2024)
     intr, mask, aspect, rt = _start(pkg, synth, ms)
     outs = []
-    for off in ("1", "0"):
-        monkeypatch.setenv("CCALIB_NO_CHAIN", off)
+    for on in ("0", "1"):
+        monkeypatch.setenv("CCALIB_CHAIN", on)
         s = pkg.Solver(obj, ms.img)
         s.set_start(intr, mask, rt)
         st = s.run(criteria=(3, 25, 1e-13))
