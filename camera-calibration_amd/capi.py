@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("CCALIB_LIB") or os.path.join(_HERE, "libccalib.so")  
 
 # every symbol include/ccalib.h declares
 SYMBOLS = [
-    "ccalib_last_error", "ccalib_version",
+    "ccalib_last_error", "ccalib_version", "ccalib_dist_coeffs_out",
     "ccalib_calibrate_camera", "ccalib_stereo_calibrate", "ccalib_reprojection_error",
     "ccalib_reprojection_error_noalloc",
     "ccalib_init_camera_matrix_2d", "ccalib_write_mono_yaml", "ccalib_write_stereo_yaml",

@@ -173,7 +173,9 @@ __global__ __launch_bounds__(kBlock) void k_err_wave(PassArgs a, CamParams cp, c
     const int nwaves = gridDim.x * kWaves;
     double acc[1] = {0.};
     for (int v = __builtin_amdgcn_readfirstlane(blockIdx.x * kWaves + w); v < a.nviews; v += nwaves) {
-        const int first = a.off[v], np = a.off[v + 1] - first;
+        // a shared board means equal point counts: no trip to the offset table before the points can be asked for
+        const int first = a.shared_board ? v * a.board_np : a.off[v];
+        const int np = a.shared_board ? a.board_np : a.off[v + 1] - first;
         const double* q = pc + kPoseConstStride * (size_t)v;  // wave-uniform: scalar loads
         const double ax = q[0], ay = q[1], az = q[2], c = q[3], c1 = q[4], sn = q[5], tx = q[10], ty = q[11], tz = q[12];
         for (int p0 = 0; p0 < np; p0 += 64) {

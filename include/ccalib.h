@@ -70,6 +70,15 @@ enum {
 };
 enum { CCALIB_TERM_COUNT = 1, CCALIB_TERM_EPS = 2 };
 
+/*
+ * How many distortion coefficients cv::calibrateCamera / cv::calibrateCameraRO (stereo = 0) or cv::stereoCalibrate
+ * (stereo = 1) of OpenCV 4.1.0 hand back for a flag word (calibration.cpp, recalled -- OpenCV is not part of the
+ * reference tree): the vector is prepared with 14 entries (12 in calibrateCamera under CALIB_THIN_PRISM_MODEL without
+ * CALIB_TILTED_MODEL) and cut back to 5 unless one of RATIONAL / THIN_PRISM / TILTED is set.  Both C++ adaptors
+ * (ccalib.hpp, ccalib_cv.hpp) size their outputs with it.
+ */
+int ccalib_dist_coeffs_out(int flags, int stereo);
+
 typedef struct {
     int iters;          /* accepted LM iterations (CvLevMarq::iters)                    */
     int jac_passes;     /* passes over all points that evaluated residuals + Jacobians  */

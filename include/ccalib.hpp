@@ -66,12 +66,8 @@ inline void flatten(const std::vector<std::vector<Point3f>>& obj, const std::vec
         for (const Point2f& p : img[i]) { m.push_back(p.x); m.push_back(p.y); }
     }
 }
-// OpenCV's prepareCameraMatrix / prepareDistCoeffs: empty -> eye(3) / zeros; output length by model
+// OpenCV's prepareCameraMatrix: empty -> eye(3).  (Output length of the distortion vector: ccalib_dist_coeffs_out.)
 inline Mat camera_or_eye(const Mat& K) { return K.total() == 9 ? K : Mat::eye(3); }
-inline int dist_len(int flags, size_t given) {
-    if (flags & CCALIB_RATIONAL_MODEL) return given > 8 ? 14 : 8;
-    return 5;
-}
 }  // namespace detail
 
 inline double calibrateCameraRO(const std::vector<std::vector<Point3f>>& objectPoints,
@@ -83,7 +79,7 @@ inline double calibrateCameraRO(const std::vector<std::vector<Point3f>>& objectP
     std::vector<float> o, m;
     detail::flatten(objectPoints, imagePoints, npts, o, m);
     Mat K = detail::camera_or_eye(cameraMatrix);
-    int nd = detail::dist_len(flags, distCoeffs.total());
+    int nd = ccalib_dist_coeffs_out(flags, 0);
     std::vector<double> d(nd, 0.);
     for (size_t i = 0; i < distCoeffs.total() && i < d.size(); i++) d[i] = distCoeffs.v[i];
     int n = (int)npts.size();
@@ -144,7 +140,7 @@ inline double stereoCalibrate(const std::vector<std::vector<Point3f>>& objectPoi
                                           T.v.data(), E.v.data(), F.v.data(), flags, criteria.type, criteria.maxCount,
                                           criteria.epsilon, nullptr, nullptr, nullptr, &rms, nullptr));
     cameraMatrix1 = K1, cameraMatrix2 = K2;
-    int nd = (flags & CCALIB_RATIONAL_MODEL) ? 14 : 5;  // stereoCalibrate keeps 14 with the rational model, else 5
+    int nd = ccalib_dist_coeffs_out(flags, 1);
     distCoeffs1 = Mat(1, nd), distCoeffs2 = Mat(1, nd);
     distCoeffs1.v.assign(d1.begin(), d1.begin() + nd);
     distCoeffs2.v.assign(d2.begin(), d2.begin() + nd);

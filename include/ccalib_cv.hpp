@@ -18,6 +18,7 @@
 
 #ifdef CCALIB_CV_AVAILABLE
 #include <cfloat>
+#include <opencv2/calib3d.hpp>  // the CALIB_* flags
 #include <opencv2/core.hpp>
 #include <vector>
 
@@ -50,11 +51,6 @@ inline cv::Mat as_f64(const cv::Mat& a, int rows, int cols, bool identity) {
     }
     return r;
 }
-inline int dist_count(const cv::Mat& d, int flags) {
-    int n = (int)d.total();
-    if (n == 4 || n == 5 || n == 8 || n == 12 || n == 14) return n;
-    return (flags & cv::CALIB_RATIONAL_MODEL) ? 8 : 5;
-}
 inline void split_poses(const cv::Mat& rv, const cv::Mat& tv, std::vector<cv::Mat>& rvecs, std::vector<cv::Mat>& tvecs) {
     rvecs.resize(rv.rows), tvecs.resize(tv.rows);
     for (int i = 0; i < rv.rows; i++) rvecs[i] = rv.row(i).t(), tvecs[i] = tv.row(i).t();
@@ -69,7 +65,7 @@ inline double calibrateCamera(const std::vector<std::vector<cv::Point3f>>& objec
     std::vector<int> npts;
     std::vector<float> o, m;
     flatten(objectPoints, imagePoints, npts, o, m);
-    const int n = (int)npts.size(), nd = dist_count(distCoeffs, flags);
+    const int n = (int)npts.size(), nd = ccalib_dist_coeffs_out(flags, 0);
     cv::Mat K = as_f64(cameraMatrix, 3, 3, true), D = as_f64(distCoeffs, nd, 1, false), rv(n, 3, CV_64F), tv(n, 3, CV_64F);
     double rms = 0;
     check(ccalib_calibrate_camera(n, npts.data(), o.data(), m.data(), imageSize.width, imageSize.height, K.ptr<double>(),
@@ -113,9 +109,7 @@ inline double stereoCalibrate(const std::vector<std::vector<cv::Point3f>>& objec
                                   D1.ptr<double>(), K2.ptr<double>(), D2.ptr<double>(), imageSize.width, imageSize.height,
                                   R.ptr<double>(), T.ptr<double>(), E.ptr<double>(), F.ptr<double>(), flags, crit.type,
                                   crit.maxCount, crit.epsilon, nullptr, nullptr, nullptr, &rms, nullptr));
-    // OpenCV returns 5, 8, 12 or 14 coefficients according to the model the flags select
-    const int nd = (flags & cv::CALIB_TILTED_MODEL) ? 14 : (flags & cv::CALIB_THIN_PRISM_MODEL) ? 12
-                   : (flags & cv::CALIB_RATIONAL_MODEL) ? 8 : 5;
+    const int nd = ccalib_dist_coeffs_out(flags, 1);
     cameraMatrix1 = K1, cameraMatrix2 = K2;
     distCoeffs1 = D1.rowRange(0, nd).clone(), distCoeffs2 = D2.rowRange(0, nd).clone();
     return rms;
