@@ -41,7 +41,7 @@ MFMA_FLOPS = 2 * 4 * (4 * 4 * 4)     # v_mfma_f64_4x4x4_4b_f64: four 4x4x4 block
 BYTES_JAC_VIEW = (8 * 54 + 104 + 8 * (21 + 6 + 6 * 9)) / 54.0   # image points + pose record in, blocks out, per point
 PEAK_FP64_TFLOPS = 78.6    # MI355X dense FP64, matrix and vector alike (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
 PEAK_HBM_GBPS = 8000.0
-PROFILE_PMC = os.path.join(ROOT, "profiles", "r01_bench_hbm_pmc_v12.json")   # rocprofv3 FETCH_SIZE / WRITE_SIZE passes
+PROFILE_PMC = os.path.join(ROOT, "profiles", "r02_bench_pmc.json")   # rocprofv3 FETCH_SIZE / WRITE_SIZE passes
 # stereoCalibrate with the reference's flag set: per camera fy cx cy k1 k2 k6 free, fx tied, rational model
 # (oracle/flopcount.py, stereo_reference_flags_6col_per_camera); a point pair is one point in each camera
 FLOPS_STEREO_PER_CAMERA_POINT = 473
