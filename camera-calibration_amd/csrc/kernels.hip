@@ -172,7 +172,67 @@ __global__ __launch_bounds__(kBlock) void k_err_wave(PassArgs a, CamParams cp, c
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nwaves = gridDim.x * kWaves;
     double acc[1] = {0.};
-    for (int v = __builtin_amdgcn_readfirstlane(blockIdx.x * kWaves + w); v < a.nviews; v += nwaves) {
+    int v = __builtin_amdgcn_readfirstlane(blockIdx.x * kWaves + w);
+    if (a.shared_board && a.board_np <= 64) {
+        // Every view is the same board of at most 64 points: a lane's object point never changes and is read once.
+        // A view is ~0.15 us of arithmetic and a memory round trip ~2 us, which eight wavefronts per SIMD taking one
+        // view at a time do not cover (56 % of SIMD time in vector instructions, measured).  So a wavefront takes
+        // four consecutive views at a time and asks for the next four while it works: one 512-byte load brings
+        // their four pose records (lane l: double l%16 of record l/16), four more the image points.  The records
+        // reach all lanes through a 512-byte LDS slot per wavefront (broadcast reads).  Nothing in the loop is a
+        // scalar load, so no wait drains more than it needs.
+        __shared__ double recs[kWaves][64];
+        const int np = a.board_np;
+        const bool on = lane < np;
+        const float* ob = lds_dyn + 3 * (on ? lane : 0);
+        const double X = ob[0], Y = ob[1], Z = ob[2];
+        constexpr int GV = 4;  // views per trip
+        const int ngroups = (a.nviews + GV - 1) / GV;
+        struct Group {
+            double rec;
+            float2 m[GV];
+        };
+        auto fetch = [&](int g) {
+            Group r;
+            const int vr = min(GV * g + min(lane >> 4, GV - 1), a.nviews - 1);
+            r.rec = pc[kPoseConstStride * (size_t)vr + (lane & 15)];
+#pragma unroll
+            for (int j = 0; j < GV; j++) {
+                const int vj = min(GV * g + j, a.nviews - 1);
+                r.m[j] = on ? a.img[(size_t)vj * np + lane] : make_float2(0.f, 0.f);
+            }
+            return r;
+        };
+        int g = v;  // one group per wavefront and trip
+        Group h = {};
+        if (g < ngroups) h = fetch(g);
+        while (g < ngroups) {
+            const int gn = g + nwaves;
+            Group hn = {};
+            if (gn < ngroups) hn = fetch(gn);
+            __builtin_amdgcn_wave_barrier();
+            recs[w][lane] = h.rec;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < GV; j++) {
+                const double* q = recs[w] + 16 * j;
+                const double ax = q[0], ay = q[1], az = q[2], c = q[3], c1 = q[4], sn = q[5], tx = q[10], ty = q[11], tz = q[12];
+                if (on && GV * g + j < a.nviews) {
+                    const double d = c1 * (ax * X + ay * Y + az * Z);
+                    const double Xc = tx + c * X + d * ax + sn * (ay * Z - az * Y);
+                    const double Yc = ty + c * Y + d * ay + sn * (az * X - ax * Z);
+                    const double Zc = tz + c * Z + d * az + sn * (ax * Y - ay * X);
+                    PointOut<M> o;
+                    point_eval<M, false, false>(Xc, Yc, Zc, (double)h.m[j].x, (double)h.m[j].y, cp, o);
+                    acc[0] += o.ex * o.ex + o.ey * o.ey;
+                }
+            }
+            h = hn;
+            g = gn;
+        }
+        v = a.nviews;
+    }
+    for (; v < a.nviews; v += nwaves) {
         // a shared board means equal point counts: no trip to the offset table before the points can be asked for
         const int first = a.shared_board ? v * a.board_np : a.off[v];
         const int np = a.shared_board ? a.board_np : a.off[v + 1] - first;
