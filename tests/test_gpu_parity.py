@@ -312,6 +312,46 @@ def test_stereo_other_column_sets_and_ragged_views(pkg, orc, synth, case):
         assert got["K1"][0, 0] / got["K1"][1, 1] == pytest.approx(K1[0, 0] / K1[1, 1], rel=1e-12)
 
 
+@pytest.mark.parametrize("case", ["reference6", "aspect8", "plain9", "rational_aspect11", "rational12"])
+def test_stereo_sum_kernels_agree_for_every_column_set(pkg, synth, monkeypatch, case):
+    """The stereo Schur sums have two kernels (four lanes per view for small problems, one lane per view in three
+    passes for large ones; size picks one) and the column sums two ways to reach the host (from the last workgroup
+    or from a publishing kernel; column count picks one).  The same six LM iterations through each: the two sum
+    kernels add in different orders, so they agree to round-off, not bitwise; the two ways of publishing carry
+    the same numbers, so they agree bitwise.  (The parity tests against the oracle run whichever the size picks.)"""
+    obj = synth.chessboard(9, 6, 25.0)
+    st = synth.make_stereo(obj, 150, 977)     # 150 views: two full 64-view workgroups and a ragged third
+    K1 = pkg.init_camera_matrix_2d(obj, st.img1, (640, 480))
+    K2 = pkg.init_camera_matrix_2d(obj, st.img2, (640, 480))
+    flags = pkg.CALIB_USE_INTRINSIC_GUESS
+    if case == "reference6":
+        flags |= (pkg.CALIB_FIX_ASPECT_RATIO | pkg.CALIB_ZERO_TANGENT_DIST | pkg.CALIB_SAME_FOCAL_LENGTH |
+                  pkg.CALIB_RATIONAL_MODEL | pkg.CALIB_FIX_K3 | pkg.CALIB_FIX_K4 | pkg.CALIB_FIX_K5)
+    elif case == "aspect8":
+        flags |= pkg.CALIB_FIX_ASPECT_RATIO
+    elif case == "rational_aspect11":
+        flags |= pkg.CALIB_RATIONAL_MODEL | pkg.CALIB_FIX_ASPECT_RATIO
+    elif case == "rational12":
+        flags |= pkg.CALIB_RATIONAL_MODEL
+    crit = (1, 6, 0.0)
+    outs = {}
+    for quad, split in (("1", "0"), ("0", "0"), ("0", "1"), ("1", "1")):
+        monkeypatch.setenv("CCALIB_SUMS_QUAD", quad)
+        monkeypatch.setenv("CCALIB_SPLIT_PUBLISH", split)
+        outs[quad, split] = pkg.stereo_calibrate(obj, st.img1, st.img2, K1, None, K2, None, (640, 480), flags, criteria=crit)
+    for quad in "01":
+        a, b = outs[quad, "0"], outs[quad, "1"]
+        assert a["rms"] == b["rms"] and a["iters"] == b["iters"]
+        for key in ("K1", "K2", "d1", "d2", "R", "T", "rt"):
+            assert np.array_equal(a[key], b[key]), (quad, key)
+    a, b = outs["1", "0"], outs["0", "0"]
+    assert a["iters"] == b["iters"]
+    assert abs(a["rms"] - b["rms"]) <= 1e-10 * b["rms"]
+    for key in ("K1", "K2", "R", "T"):
+        assert np.abs(a[key] - b[key]).max() <= 1e-8 * np.abs(b[key]).max(), key
+    assert np.abs(a["rt"] - b["rt"]).max() < 1e-7
+
+
 def test_config5_shape_17x12_board_stereo_and_mono(pkg, orc, synth):
     """BASELINE config 5's shape at a size the dense oracle solves: 17x12 board (204 points per view, so
     every view spans four 64-point chunks of the fused kernel), both cameras with k1-k3, p1, p2 free."""
