@@ -8,7 +8,7 @@
 // Same argument order, flag values and TermCriteria semantics as OpenCV 4.1.0; errors are thrown
 // as ccalib::Exception where OpenCV throws cv::Exception.  OpenCV itself is not needed: the POD
 // types below stand in for cv::Point2f / Point3f / Size / Mat.  With OpenCV present, a maintainer
-// maps them one to one (see INTEGRATION.md).
+// maps them one to one.
 #pragma once
 #include <cfloat>
 #include <stdexcept>

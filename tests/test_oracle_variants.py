@@ -2,9 +2,9 @@
 
 The oracle restates OpenCV from memory; two details could not be checked against its text: the principal-point seed
 of cvInitIntrinsicParams2D ((w-1)/2 vs w/2) and whether CALIB_SAME_FOCAL_LENGTH masks camera 1's focal lengths or
-only overwrites them.  These tests run the oracle both ways on BASELINE configs[0] and a reduced configs[2] and
-bound the difference, so that a maintainer comparing against a real OpenCV knows the signature of either mismatch.
-The measured figures are recorded in DESIGN.md.
+only overwrites them.  These tests run the oracle both ways on the 20-view monocular configuration and a reduced configs[2] and
+bound the difference, so that a maintainer comparing against a real OpenCV knows the signature of either mismatch
+(each test prints the figures it measured).
 """
 import numpy as np
 
