@@ -10,4 +10,6 @@ int set_error(int code, const char* fmt, ...);
 bool solve_lu(std::vector<double> A, std::vector<double>& b, int n);
 void solve_sym_svd(const std::vector<double>& A, std::vector<double>& b, int n);
 void eig_sym(std::vector<double> A, int n, std::vector<double>& w, std::vector<double>& V);
+void lm_trial_step(int ns, int nf, const int* fidx, const double* U, const double* gs, const double* Ssum,
+                   const double* bsum, double lambda, int solve_method, const double* prev, double* shared, double* dsh);
 }  // namespace ccalib

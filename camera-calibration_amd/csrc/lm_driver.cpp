@@ -123,6 +123,34 @@ void solve_sym_svd(const std::vector<double>& A, std::vector<double>& b, int n) 
     b = x;
 }
 
+// One CvLevMarq::step(): the reduced system S = U' - Ssum, b = gs - bsum over the free set (U' = U mirrored, its
+// diagonal times 1 + lambda), its solution, and the trial point shared = prev - solution on the free entries.  The
+// driver below and a backend that predicts the driver's next step both call this, so the two cannot differ by a bit.
+void lm_trial_step(int ns, int nf, const int* fidx, const double* U, const double* gs, const double* Ssum,
+                   const double* bsum, double lambda, int solve_method, const double* prev, double* shared, double* dsh) {
+    std::vector<double> S((size_t)nf * nf), b(nf);
+    for (int a = 0; a < nf; a++) {
+        for (int c = 0; c < nf; c++) {
+            int ia = fidx[a], ic = fidx[c];
+            double u = ia <= ic ? U[(size_t)ia * ns + ic] : U[(size_t)ic * ns + ia];  // completeSymm
+            if (a == c) u *= 1. + lambda;
+            S[(size_t)a * nf + c] = u - Ssum[(size_t)a * nf + c];
+        }
+        b[a] = gs[fidx[a]] - bsum[a];
+    }
+    if (nf > 0) {
+        if (solve_method == 0) {
+            if (!solve_lu(S, b, nf)) std::fill(b.begin(), b.end(), 0.);  // cv::solve leaves zeros
+        } else
+            solve_sym_svd(S, b, nf);
+    }
+    for (int i = 0; i < ns; i++) shared[i] = prev[i];
+    for (int a = 0; a < nf; a++) {
+        dsh[a] = b[a];
+        shared[fidx[a]] = prev[fidx[a]] - b[a];
+    }
+}
+
 }  // namespace ccalib
 
 using namespace ccalib;
@@ -168,27 +196,8 @@ extern "C" int ccalib_lm_run(const ccalib_backend* be, void* user, double* share
     auto step_and_eval = [&](double& err_out) -> int {
         double lambda = lam(lambdaLg10);
         if ((rc = be->reduce(user, lambda, fidx.data(), nf, Ssum.data(), bsum.data()))) return rc;
-        std::vector<double> S((size_t)nf * nf), b(nf);
-        for (int a = 0; a < nf; a++) {
-            for (int c = 0; c < nf; c++) {
-                int ia = fidx[a], ic = fidx[c];
-                double u = ia <= ic ? U[(size_t)ia * ns + ic] : U[(size_t)ic * ns + ia];  // completeSymm
-                if (a == c) u *= 1. + lambda;
-                S[(size_t)a * nf + c] = u - Ssum[(size_t)a * nf + c];
-            }
-            b[a] = gs[fidx[a]] - bsum[a];
-        }
-        if (nf > 0) {
-            if (solve_method == 0) {
-                if (!solve_lu(S, b, nf)) std::fill(b.begin(), b.end(), 0.);  // cv::solve leaves zeros
-            } else
-                solve_sym_svd(S, b, nf);
-        }
-        for (int i = 0; i < ns; i++) shared[i] = prev[i];
-        for (int a = 0; a < nf; a++) {
-            dsh[a] = b[a];
-            shared[fidx[a]] = prev[fidx[a]] - b[a];
-        }
+        lm_trial_step(ns, nf, fidx.data(), U.data(), gs.data(), Ssum.data(), bsum.data(), lambda, solve_method, prev.data(),
+                      shared, dsh.data());
         if (be->fixup) be->fixup(user, shared, prev.data());
         err_passes++;
         return be->step_err(user, lambda, lam(std::max(lambdaLg10 - 1, -16)), fidx.data(), nf, dsh.data(), shared, &dn2,

@@ -148,6 +148,26 @@ struct ccalib_solver {
     // One iteration run ahead of the host (lm_step.hpp): the kernels of the next trial step are enqueued before the
     // host has seen the sums of the current one and take their parameters from a control block the device writes.
     int split_publish = -1;          // CCALIB_SPLIT_PUBLISH=0/1 forces where the sums are published from (-1: by size)
+    // A retry launched behind a trial that the damping history says will be rejected (be_step_err): the kernels of
+    // the step the driver is expected to ask for next are already in the stream when it asks.
+    struct Trial {
+        Pending p;
+        int n = 0;
+        bool ahead = false, predicted = false;
+        double lam2 = 0.;
+    };
+    struct Retry {
+        bool inflight = false;
+        double lambda = 0, lambda_next = 0;
+        int nf = 0, cur = 0;
+        double dsh[42], shared[42];
+        Trial t;
+    } retry;
+    bool retry_enabled = true;            // CCALIB_NO_RETRY_AHEAD=1 turns it off
+    double* d_pose_retry = nullptr;       // trial poses of such a retry (they must not touch the first trial's)
+    std::vector<double> com_U, com_gs;    // shared block and gradient of the committed Jacobian, as the driver holds them
+    double com_shared[42];                // the committed point
+    bool com_valid = false;
     bool chain_enabled = false;      // CCALIB_CHAIN=1 turns running ahead of the host on (measured: no gain)
     LmCtrl* d_ctrl = nullptr;        // [2], indexed by the slot of the iteration that reads it
     LmMaps* d_maps = nullptr;
@@ -655,9 +675,17 @@ int be_jac(void* user, const double* shared, double lambda_hint, double* U, doub
         s->have_cached = true;
         s->have_cached2 = s->spec_have2;
         if (s->spec_have2) s->cachedS2 = s->spec_S2, s->cached_lambda2 = s->spec_lambda2;
+        s->com_U.assign(U, U + (size_t)ns * ns), s->com_gs.assign(gs, gs + ns);
+        std::memcpy(s->com_shared, shared, sizeof(double) * ns);
+        s->com_valid = true;
         return CCALIB_OK;
     }
     s->spec_valid = false;
+    if (s->retry.inflight) {  // the first trial was accepted after all: the retry behind it runs to its end unused
+        s->retry.inflight = false;
+        s->pc_fresh = s->pc3_fresh = false;  // the pose records are the retry's
+        s->n_ahead_dropped++;
+    }
     if (s->chain.inflight) {  // an iteration run ahead from a point the driver did not go to
         s->chain.inflight = false;
         s->pc_fresh = false;
@@ -689,6 +717,29 @@ int be_jac(void* user, const double* shared, double lambda_hint, double* U, doub
     if (lam2 != 0.) s->cachedS2.assign(s->h_red[p.slot] + L0.end, s->h_red[p.slot] + L0.end + L0.nsum), s->cached_lambda2 = lam2;
     s->last_err = *err;
     if (s->run_first_jac) s->drv_err = *err, s->run_first_jac = false;
+    s->com_U.assign(U, U + (size_t)ns * ns), s->com_gs.assign(gs, gs + ns);
+    std::memcpy(s->com_shared, shared, sizeof(double) * ns);
+    s->com_valid = true;
+    return CCALIB_OK;
+}
+
+// Schur sums in kernel-column order (packed upper triangle, then right-hand side) -> the driver's free set
+int map_schur_sums(const ccalib_solver* s, const std::vector<double>& S, const int* fidx, int nf, double* Ssum, double* bsum) {
+    const int kc = s->kcols();
+    std::vector<int> s2k(s->ns(), -1);
+    for (int k = 0; k < kc; k++)
+        if (s->kcol_to_shared(k) < s->ns()) s2k[s->kcol_to_shared(k)] = k;
+    auto tri = [kc](int a, int b) { return a * kc - a * (a - 1) / 2 + (b - a); };
+    for (int a = 0; a < nf; a++) {
+        int ka = s2k[fidx[a]];
+        if (ka < 0) return set_error(CCALIB_ERR_STATE, "free parameter %d is not a kernel column", fidx[a]);
+        for (int c = 0; c < nf; c++) {
+            int kb = s2k[fidx[c]];
+            if (kb < 0) return set_error(CCALIB_ERR_STATE, "free parameter %d is not a kernel column", fidx[c]);
+            Ssum[(size_t)a * nf + c] = S[ka <= kb ? tri(ka, kb) : tri(kb, ka)];
+        }
+        bsum[a] = S[kc * (kc + 1) / 2 + ka];
+    }
     return CCALIB_OK;
 }
 
@@ -711,28 +762,123 @@ int be_reduce(void* user, double lambda, const int* fidx, int nf, double* Ssum, 
         s->cached_lambda = lambda;
         s->have_cached = true;
     }
-    // kernel-column space -> the driver's free set
-    std::vector<int> s2k(s->ns(), -1);
-    for (int k = 0; k < kc; k++)
-        if (s->kcol_to_shared(k) < s->ns()) s2k[s->kcol_to_shared(k)] = k;
-    auto tri = [kc](int a, int b) { return a * kc - a * (a - 1) / 2 + (b - a); };
-    for (int a = 0; a < nf; a++) {
-        int ka = s2k[fidx[a]];
-        if (ka < 0) return set_error(CCALIB_ERR_STATE, "free parameter %d is not a kernel column", fidx[a]);
-        for (int c = 0; c < nf; c++) {
-            int kb = s2k[fidx[c]];
-            if (kb < 0) return set_error(CCALIB_ERR_STATE, "free parameter %d is not a kernel column", fidx[c]);
-            Ssum[(size_t)a * nf + c] = s->cachedS[ka <= kb ? tri(ka, kb) : tri(kb, ka)];
-        }
-        bsum[a] = s->cachedS[kc * (kc + 1) / 2 + ka];
-    }
-    return CCALIB_OK;
+    return map_schur_sums(s, s->cachedS, fidx, nf, Ssum, bsum);
 }
 
 // The trial point's residual sum comes either from the residual kernels or, when the step is
 // likely to be accepted, from a whole Jacobian pass run ahead into the spare buffer: the driver's
 // next call is then jac() at this same point, which be_jac answers without touching the GPU.
 // A rejected step only costs the extra work; the committed Jacobian stays in buffer `cur`.
+
+void be_fixup(void* user, double* shared, double* prev);
+
+// Enqueues a trial step -- back-substitution into s->d_pose_cur, then either the Jacobian pass run ahead or the
+// residual pass -- and submits its reduction.  Does not wait.
+int launch_trial(ccalib_solver* s, double lambda, double lambda_next, const int* fidx, int nf, const double* dshared,
+                 const double* shared_new, ccalib_solver::Trial* t) {
+    int rc;
+    const int cur = s->cur, ns = s->ns();
+    bool stereo_composed = false;
+    std::vector<double> dfull(ns, 0.);
+    for (int a = 0; a < nf; a++) dfull[fidx[a]] = dshared[a];
+    const bool ahead = s->speculate && s->level_accepted[lambda_level(lambda)];
+    PART_TAKE(npart, s, (size_t)s->nblk64 * 2);
+    if (s->ncams == 1) {
+        DeltaC dc;
+        for (int k = 0; k < I_NMODEL; k++) dc.v[k] = 0;
+        for (int k = 0; k < s->ops[0]->NC; k++) dc.v[k] = dfull[s->ops[0]->col(k)];
+        const bool want_pc = s->ops[0]->jac_fused && s->use_fused;
+        s->ops[0]->backsub(s->d_blk[0][cur], s->npad, s->nviews, lambda, dc, s->d_pose_prev, s->d_pose_cur, npart,
+                           want_pc ? s->d_pc : nullptr, s->stream, nullptr);
+        s->pc_fresh = want_pc;
+    } else {
+        StereoDelta sd;
+        int kc = s->kcols();
+        for (int k = 0; k < kStereoMaxCols; k++)
+            sd.v[k] = k < kc && s->kcol_to_shared(k) < ns ? dfull[s->kcol_to_shared(k)] : 0.;
+        const bool want_pc = s->ops[0]->jac_fused && s->use_fused;
+        // a residual pass follows unless the next Jacobian pass is run ahead (which composes with derivatives):
+        // camera 1's trial poses then come out of this kernel too
+        const bool compose_here = !ahead;
+        StereoLR lr_new;
+        for (int i = 0; i < 6; i++) lr_new.v[i] = shared_new[i];
+        if (!launch_stereo_backsub(s->ops[0]->NC, s->d_blk[0][cur], s->d_blk[1][cur], s->d_cmp[cur], s->lr_jac[cur],
+                                   s->npad, s->nviews, lambda, sd, s->d_pose_prev, s->d_pose_cur, npart,
+                                   want_pc ? s->d_pc : nullptr, lr_new, compose_here ? s->d_pose3 : nullptr,
+                                   compose_here ? s->d_pc3 : nullptr, s->stream))
+            return set_error(CCALIB_ERR_UNSUPPORTED, "stereo column count %d is not built in", s->ops[0]->NC);
+        s->pc_fresh = want_pc;
+        s->pc3_fresh = compose_here;
+        stereo_composed = compose_here;
+    }
+    if ((rc = queue_colsum(s, npart, s->nblk64, 2, 0))) return rc;
+    store_shared(s, shared_new);
+    t->ahead = ahead;
+    t->predicted = false;
+    t->lam2 = 0.;
+    if (ahead) {
+        t->lam2 = retry_lambda(s, lambda_next);
+        if ((rc = enqueue_jac(s, cur ^ 1, lambda_next, 2, s->d_pose_cur, nullptr, t->lam2))) return rc;
+        const JacLayout L0 = jac_layout(s);
+        t->n = 2 + L0.end + (t->lam2 != 0. ? L0.nsum : 0);
+        if (chain_possible(s)) {
+            t->predicted = s->commits < s->run_max_iter && s->level_accepted[lambda_level(lambda_next)];
+            LmStepArgs st;
+            fill_step(s, st, 2, lambda_next, s->committed_err, shared_new, t->predicted);
+            if ((rc = submit_reduction(s, t->n, nullptr, &st, &t->p))) return rc;
+            if (t->predicted && (rc = enqueue_chain(s, lambda_next, cur ^ 1, s->d_pose_cur, s->d_pose_prev))) return rc;
+        } else if ((rc = submit_reduction(s, t->n, nullptr, nullptr, &t->p)))
+            return rc;
+    } else {
+        // residual pass at the trial point
+        if (!stereo_composed && (rc = stereo_compose(s, false, cur, s->d_pose_cur))) return rc;
+        for (int c = 0; c < s->ncams; c++) {
+            CamParams cp = cam_params(s->intr[c], s->aspect[c]);
+            PART_TAKE(epart, s, (size_t)s->grid_err);
+            enqueue_err(s, c, cp, epart);
+            if ((rc = queue_colsum(s, epart, s->grid_err, 1, 2 + c))) return rc;
+        }
+        t->n = 2 + s->ncams;
+        if ((rc = submit_reduction(s, t->n, nullptr, nullptr, &t->p))) return rc;
+    }
+    return CCALIB_OK;
+}
+
+// After a trial that the damping history says will be rejected: the driver will then raise the damping one decade
+// and step again from the same Jacobian.  When the Schur sums for that damping are already here (they were taken
+// along with the Jacobian pass), its step can be worked out now -- with the very function the driver uses -- and its
+// kernels put into the stream behind the first trial's, so that the GPU does not idle through a host turn-around
+// between the two.  The retry writes its poses to a buffer of its own; the driver's call is answered from it only
+// when damping, step and trial point are bit for bit the ones prepared here.
+int launch_retry_ahead(ccalib_solver* s, double lambda, const int* fidx, int nf) {
+    ccalib_solver::Retry& r = s->retry;
+    const int lv = lambda_level(lambda), ns = s->ns();
+    if (!s->retry_enabled || !s->speculate || chain_possible(s) || !s->com_valid || s->cb || lv >= 32 || nf > 42) return CCALIB_OK;
+    if (s->level_accepted[lv] || !s->level_accepted[lv + 1]) return CCALIB_OK;  // only the pattern "rejected, then accepted"
+    const double lambda2 = std::exp((lv + 1 - 16) * std::log(10.));
+    if (!s->have_cached2 || s->cached_lambda2 != lambda2) return CCALIB_OK;
+    std::vector<double> Ssum((size_t)nf * nf), bsum(nf);
+    int rc = map_schur_sums(s, s->cachedS2, fidx, nf, Ssum.data(), bsum.data());
+    if (rc) return rc;
+    double prev[42];
+    std::memcpy(prev, s->com_shared, sizeof(double) * ns);
+    lm_trial_step(ns, nf, fidx, s->com_U.data(), s->com_gs.data(), Ssum.data(), bsum.data(), lambda2, s->run_solve_method, prev,
+                  r.shared, r.dsh);
+    be_fixup(s, r.shared, prev);
+    // as be_step_err will see the damping history when the driver asks: this level rejected
+    const bool was = s->level_accepted[lv];
+    s->level_accepted[lv] = false;
+    std::swap(s->d_pose_cur, s->d_pose_retry);
+    rc = launch_trial(s, lambda2, lambda, fidx, nf, r.dsh, r.shared, &r.t);
+    std::swap(s->d_pose_cur, s->d_pose_retry);
+    s->level_accepted[lv] = was;
+    if (rc) return rc;
+    r.lambda = lambda2, r.lambda_next = lambda, r.nf = nf, r.cur = s->cur;
+    r.inflight = true;
+    s->n_ahead++;
+    return CCALIB_OK;
+}
+
 // When the device has already run this very step ahead of the host (same damping, and the step the driver
 // computed is bit for bit the one k_lm_step predicted), its sums are simply waited for.
 int be_step_err(void* user, double lambda, double lambda_next, const int* fidx, int nf, const double* dshared,
@@ -747,11 +893,8 @@ int be_step_err(void* user, double lambda, double lambda_next, const int* fidx, 
     s->steps_since_jac++;
     s->spec_valid = false;
     s->have_cached = false;
-    const double* red = nullptr;
-    bool have_jac = false, predicted = false;
-    int jac_slot = 0;
-    double lam2 = 0.;  // damping of a second set of Schur sums taken along with the pass run ahead
-    bool stereo_composed = false;
+    ccalib_solver::Trial t;
+    bool launched = false;
 
     ccalib_solver::Chain& ch = s->chain;
     if (ch.inflight) {
@@ -762,15 +905,15 @@ int be_step_err(void* user, double lambda, double lambda_next, const int* fidx, 
         ch.inflight = false;
         if (match) {
             // the GPU is already on this step; queue the one after it, then wait for this one's sums
-            const Pending pend = ch.pend;
-            predicted = ch.predicts;
+            t.p = ch.pend;
+            t.predicted = ch.predicts;
+            t.ahead = true;
+            t.lam2 = 0.;
+            t.n = 2 + jac_layout(s).end;
             store_shared(s, shared_new);
             s->pc_fresh = true;
-            if (predicted && (rc = enqueue_chain(s, lambda_next, cur ^ 1, s->d_pose_cur, s->d_pose_prev))) return rc;
-            if ((rc = wait_reduction(s, pend, 2 + jac_layout(s).end))) return rc;
-            red = s->h_red[pend.slot];
-            jac_slot = pend.slot;
-            have_jac = true;
+            if (t.predicted && (rc = enqueue_chain(s, lambda_next, cur ^ 1, s->d_pose_cur, s->d_pose_prev))) return rc;
+            launched = true;
             s->n_ahead_used++;
         } else {
             // called off on the device (its go word is 0: nothing ran) or not the step the driver took (it runs to
@@ -779,88 +922,49 @@ int be_step_err(void* user, double lambda, double lambda_next, const int* fidx, 
             s->n_ahead_dropped++;
         }
     }
-    if (!have_jac) {
-        std::vector<double> dfull(ns, 0.);
-        for (int a = 0; a < nf; a++) dfull[fidx[a]] = dshared[a];
-        PART_TAKE(npart, s, (size_t)s->nblk64 * 2);
-        if (s->ncams == 1) {
-            DeltaC dc;
-            for (int k = 0; k < I_NMODEL; k++) dc.v[k] = 0;
-            for (int k = 0; k < s->ops[0]->NC; k++) dc.v[k] = dfull[s->ops[0]->col(k)];
-            const bool want_pc = s->ops[0]->jac_fused && s->use_fused;
-            s->ops[0]->backsub(s->d_blk[0][cur], s->npad, s->nviews, lambda, dc, s->d_pose_prev, s->d_pose_cur, npart,
-                               want_pc ? s->d_pc : nullptr, s->stream, nullptr);
-            s->pc_fresh = want_pc;
+    ccalib_solver::Retry& r = s->retry;
+    if (r.inflight) {
+        r.inflight = false;
+        const bool ahead_now = s->speculate && s->level_accepted[s->last_level];
+        const bool match = !launched && r.lambda == lambda && r.lambda_next == lambda_next && r.nf == nf && r.cur == cur &&
+                           r.t.ahead == ahead_now && (!ahead_now || r.t.lam2 == retry_lambda(s, lambda_next)) &&
+                           std::memcmp(dshared, r.dsh, sizeof(double) * nf) == 0 &&
+                           std::memcmp(shared_new, r.shared, sizeof(double) * ns) == 0;
+        if (match) {
+            std::swap(s->d_pose_cur, s->d_pose_retry);  // its poses are the trial poses now
+            store_shared(s, shared_new);
+            t = r.t;
+            launched = true;
+            s->n_ahead_used++;
         } else {
-            StereoDelta sd;
-            int kc = s->kcols();
-            for (int k = 0; k < kStereoMaxCols; k++)
-                sd.v[k] = k < kc && s->kcol_to_shared(k) < ns ? dfull[s->kcol_to_shared(k)] : 0.;
-            const bool want_pc = s->ops[0]->jac_fused && s->use_fused;
-            // a residual pass follows unless the next Jacobian pass is run ahead (which composes with derivatives):
-            // camera 1's trial poses then come out of this kernel too
-            const bool compose_here = !(s->speculate && s->level_accepted[s->last_level]);
-            StereoLR lr_new;
-            for (int i = 0; i < 6; i++) lr_new.v[i] = shared_new[i];
-            if (!launch_stereo_backsub(s->ops[0]->NC, s->d_blk[0][cur], s->d_blk[1][cur], s->d_cmp[cur], s->lr_jac[cur],
-                                       s->npad, s->nviews, lambda, sd, s->d_pose_prev, s->d_pose_cur, npart,
-                                       want_pc ? s->d_pc : nullptr, lr_new, compose_here ? s->d_pose3 : nullptr,
-                                       compose_here ? s->d_pc3 : nullptr, s->stream))
-                return set_error(CCALIB_ERR_UNSUPPORTED, "stereo column count %d is not built in", s->ops[0]->NC);
-            s->pc_fresh = want_pc;
-            s->pc3_fresh = compose_here;
-            stereo_composed = compose_here;
-        }
-        if ((rc = queue_colsum(s, npart, s->nblk64, 2, 0))) return rc;
-        store_shared(s, shared_new);
-        const bool ahead = s->speculate && s->level_accepted[s->last_level];
-        if (ahead) {
-            lam2 = retry_lambda(s, lambda_next);
-            if ((rc = enqueue_jac(s, cur ^ 1, lambda_next, 2, s->d_pose_cur, nullptr, lam2))) return rc;
-            const JacLayout L0 = jac_layout(s);
-            const int n = 2 + L0.end + (lam2 != 0. ? L0.nsum : 0);
-            Pending p;
-            if (chain_possible(s)) {
-                predicted = s->commits < s->run_max_iter && s->level_accepted[lambda_level(lambda_next)];
-                LmStepArgs st;
-                fill_step(s, st, 2, lambda_next, s->committed_err, shared_new, predicted);
-                if ((rc = submit_reduction(s, n, nullptr, &st, &p))) return rc;
-                if (predicted && (rc = enqueue_chain(s, lambda_next, cur ^ 1, s->d_pose_cur, s->d_pose_prev))) return rc;
-            } else if ((rc = submit_reduction(s, n, nullptr, nullptr, &p)))
-                return rc;
-            if ((rc = wait_reduction(s, p, n))) return rc;
-            red = s->h_red[p.slot];
-            jac_slot = p.slot;
-            have_jac = true;
-        } else {
-            // residual pass at the trial point
-            if (!stereo_composed && (rc = stereo_compose(s, false, cur, s->d_pose_cur))) return rc;
-            for (int c = 0; c < s->ncams; c++) {
-                CamParams cp = cam_params(s->intr[c], s->aspect[c]);
-                PART_TAKE(epart, s, (size_t)s->grid_err);
-                enqueue_err(s, c, cp, epart);
-                if ((rc = queue_colsum(s, epart, s->grid_err, 1, 2 + c))) return rc;
-            }
-            if ((rc = finish_reduction(s, 2 + s->ncams, &red))) return rc;
-            *err = red[2] + (s->ncams == 2 ? red[3] : 0.);
+            s->pc_fresh = s->pc3_fresh = false;  // the pose records are the retry's
+            s->n_ahead_dropped++;
         }
     }
-    if (have_jac) {
+    if (!launched) {
+        if ((rc = launch_trial(s, lambda, lambda_next, fidx, nf, dshared, shared_new, &t))) return rc;
+        if (!t.ahead && (rc = launch_retry_ahead(s, lambda, fidx, nf))) return rc;
+        if (s->retry.inflight) store_shared(s, shared_new);  // the solver's parameters are this trial's until the driver moves on
+    }
+    if ((rc = wait_reduction(s, t.p, t.n))) return rc;
+    const double* red = s->h_red[t.p.slot];
+    if (t.ahead) {
         s->spec_U.resize((size_t)ns * ns);
         s->spec_gs.resize(ns);
         parse_jac(s, red + 2, s->spec_U.data(), s->spec_gs.data(), &s->spec_err, s->spec_S);
-        read_prediction(s, jac_slot, predicted);
+        read_prediction(s, t.p.slot, t.predicted);
         s->spec_lambda = lambda_next;
-        s->spec_have2 = lam2 != 0.;
-        if (lam2 != 0.) {
+        s->spec_have2 = t.lam2 != 0.;
+        if (t.lam2 != 0.) {
             const JacLayout L0 = jac_layout(s);
             s->spec_S2.assign(red + 2 + L0.end, red + 2 + L0.end + L0.nsum);
-            s->spec_lambda2 = lam2;
+            s->spec_lambda2 = t.lam2;
         }
         std::memcpy(s->spec_shared, shared_new, sizeof(double) * ns);
         s->spec_valid = true;
         *err = s->spec_err;
-    }
+    } else
+        *err = red[2] + (s->ncams == 2 ? red[3] : 0.);
     *dnorm2 = red[0];
     *pnorm2 = red[1];
     s->last_err = *err;
@@ -997,6 +1101,7 @@ int ccalib_solver_create(ccalib_solver** out, int device, int ncams, int nviews,
     }
     HIP_TRY(hipMalloc(&s->d_pose_prev, sizeof(double) * 6 * nviews));
     HIP_TRY(hipMalloc(&s->d_pose_cur, sizeof(double) * 6 * nviews));
+    HIP_TRY(hipMalloc(&s->d_pose_retry, sizeof(double) * 6 * nviews));
     HIP_TRY(hipMemset(s->d_pose_prev, 0, sizeof(double) * 6 * nviews));
     HIP_TRY(hipMalloc(&s->d_pc, sizeof(double) * kPoseConstStride * nviews));
     if (ncams == 2) {
@@ -1016,6 +1121,7 @@ int ccalib_solver_create(ccalib_solver** out, int device, int ncams, int nviews,
     HIP_TRY(hipMalloc(&s->d_maps, sizeof(LmMaps)));
     std::memset(&s->h_maps, 0, sizeof(LmMaps));
     if (const char* e = std::getenv("CCALIB_CHAIN")) s->chain_enabled = std::atoi(e) != 0;
+    if (const char* e = std::getenv("CCALIB_NO_RETRY_AHEAD")) s->retry_enabled = std::atoi(e) == 0;
     if (const char* e = std::getenv("CCALIB_SPLIT_PUBLISH")) s->split_publish = std::atoi(e) != 0;
     HIP_TRY(hipMalloc(&s->d_counter, sizeof(unsigned)));
     HIP_TRY(hipMemset(s->d_counter, 0, sizeof(unsigned)));
@@ -1033,6 +1139,7 @@ void ccalib_solver_destroy(ccalib_solver* s) {
     (void)hipFree(s->d_obj), (void)hipFree(s->d_off), (void)hipFree(s->d_img[0]), (void)hipFree(s->d_img[1]);
     (void)hipFree(s->d_pose_prev), (void)hipFree(s->d_pose_cur), (void)hipFree(s->d_pose3);
     (void)hipFree(s->d_sums_tab);
+    (void)hipFree(s->d_pose_retry);
     (void)hipFree(s->d_view_tab);
     for (int b = 0; b < 2; b++) (void)hipFree(s->d_cmp[b]), (void)hipFree(s->d_blk[0][b]), (void)hipFree(s->d_blk[1][b]);
     (void)hipFree(s->d_pc), (void)hipFree(s->d_pc3), (void)hipFree(s->d_ctrl), (void)hipFree(s->d_maps);
@@ -1127,6 +1234,8 @@ int ccalib_solver_set_start(ccalib_solver* s, const double* intr, const unsigned
     int rc = build_step_maps(s);
     if (rc) return rc;
     s->chain.inflight = false;
+    s->retry.inflight = false;
+    s->com_valid = false;
     s->pred_go = false;
     s->started = true;
     s->pc_fresh = s->pc3_fresh = false;
@@ -1377,12 +1486,14 @@ int ccalib_solver_run(ccalib_solver* s, int term_type, int max_iter, double eps,
     s->commits = 0;
     s->run_first_jac = true;
     s->chain.inflight = false;
+    s->retry.inflight = false;
+    s->com_valid = false;
     s->pred_go = false;
     int rc = ccalib_lm_run(&be, s, shared, smask, term_type, max_iter, eps, solve_method, stats);
     store_shared(s, shared);
-    if (s->chain.inflight) {  // the driver stopped on its convergence test with an iteration still running ahead
-        s->chain.inflight = false;
-        s->pc_fresh = false;
+    if (s->chain.inflight || s->retry.inflight) {  // the driver stopped with work still running ahead of it
+        s->chain.inflight = s->retry.inflight = false;
+        s->pc_fresh = s->pc3_fresh = false;
         s->n_ahead_dropped++;
         HIP_TRY(hipStreamSynchronize(s->stream));
     }

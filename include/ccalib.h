@@ -265,7 +265,9 @@ int ccalib_solver_run(ccalib_solver* s, int term_type, int max_iter, double eps,
  * operations in the same order -- and the kernels of that step are already queued; the host uses them only when
  * its own step is bit for bit the predicted one, so results never depend on it).  out[0] iterations enqueued
  * ahead, out[1] of them used by the driver, out[2] dropped (step rejected, convergence reached, or no match).
- * Since the solver was created.  The mechanism is off unless CCALIB_CHAIN=1 is in the environment: measured on
+ * A retry launched behind a trial step that the damping history says will be rejected (its step worked out on the
+ * host with the driver's own function, used only on a bitwise match) is counted the same way.
+ * Since the solver was created.  The first mechanism is off unless CCALIB_CHAIN=1 is in the environment: measured on
  * MI355X it hides the host's turn-around but costs as much in device-side work, so it is kept as an option only.
  */
 int ccalib_solver_counters(ccalib_solver* s, long long out[3]);

@@ -352,6 +352,41 @@ def test_stereo_sum_kernels_agree_for_every_column_set(pkg, synth, monkeypatch, 
     assert np.abs(a["rt"] - b["rt"]).max() < 1e-7
 
 
+def test_retry_launched_behind_a_doomed_trial_changes_nothing(pkg, synth, monkeypatch):
+    """With the reference's stereo flag set every first trial of an iteration is rejected and its retry accepted.  The
+    solver then puts the retry's kernels into the stream behind the first trial's (it works the retry's step out
+    with the driver's own function while the GPU is busy) and the driver's call is answered from them only when its
+    step is bit for bit the prepared one: a run with the mechanism equals a run without it bit for bit, and the
+    counters show that it engaged."""
+    obj = synth.chessboard(9, 6, 25.0)
+    st = synth.make_stereo(obj, 3000, 0xC0FFEE + 3)
+    K = [pkg.init_camera_matrix_2d(obj, im, (640, 480)) for im in (st.img1, st.img2)]
+    intr = np.zeros((2, 18))
+    for c in range(2):
+        intr[c, :4] = [(K[0][0, 0] + K[1][0, 0]) / 2, (K[0][1, 1] + K[1][1, 1]) / 2,
+                       (K[0][0, 2] + K[1][0, 2]) / 2, (K[0][1, 2] + K[1][1, 2]) / 2]
+    mask = np.zeros((2, 18), dtype=np.uint8)
+    mask[:, [1, 2, 3, 4, 5, 11]] = 1           # fy cx cy k1 k2 k6: the reference's stereo flag set
+    aspect = [intr[0, 0] / intr[0, 1], intr[1, 0] / intr[1, 1]]
+    rt0 = synth.perturbed_poses(st.rvec, st.tvec, 3, rot_sigma=0.01, trans_sigma=3.0)
+    lr0 = np.r_[st.r_lr, st.t_lr] + np.array([1e-3, -1e-3, 5e-4, 0.5, -0.2, 0.3])
+    outs = []
+    for off in ("1", "0"):
+        monkeypatch.setenv("CCALIB_NO_RETRY_AHEAD", off)
+        s = pkg.Solver(obj, st.img1, st.img2)
+        s.set_start(intr, mask, rt0, aspect=aspect, same_focal=True, lr=lr0)
+        stt = s.run(criteria=(3, 25, 1e-12))
+        outs.append((stt, s.get(), s.counters()))
+        s.close()
+    (st0, o0, c0), (st1, o1, c1) = outs
+    assert st0["iters"] == st1["iters"] and st0["err_passes"] == st1["err_passes"]
+    assert st0["err_passes"] >= st0["iters"] + 5                   # there were rejected trials to run ahead of
+    assert o0["err"] == o1["err"]
+    for key in ("intr", "rt", "lr"):
+        assert np.array_equal(o0[key], o1[key]), key
+    assert c1["used"] >= c0["used"] + 5, (c0, c1, st1)
+
+
 def test_config5_shape_17x12_board_stereo_and_mono(pkg, orc, synth):
     """BASELINE config 5's shape at a size the dense oracle solves: 17x12 board (204 points per view, so
     every view spans four 64-point chunks of the fused kernel), both cameras with k1-k3, p1, p2 free."""
