@@ -772,6 +772,13 @@ int be_reduce(void* user, double lambda, const int* fidx, int nf, double* Ssum, 
 
 void be_fixup(void* user, double* shared, double* prev);
 
+// Whether a trial at this damping gets the Jacobian pass of its trial point run ahead (instead of a residual pass):
+// when the last trial at this level was accepted -- and not in the run's last iteration, whose accepted point the
+// driver never asks a Jacobian for.
+bool trial_runs_ahead(const ccalib_solver* s, double lambda) {
+    return s->speculate && s->level_accepted[lambda_level(lambda)] && s->commits < s->run_max_iter;
+}
+
 // Enqueues a trial step -- back-substitution into s->d_pose_cur, then either the Jacobian pass run ahead or the
 // residual pass -- and submits its reduction.  Does not wait.
 int launch_trial(ccalib_solver* s, double lambda, double lambda_next, const int* fidx, int nf, const double* dshared,
@@ -781,7 +788,7 @@ int launch_trial(ccalib_solver* s, double lambda, double lambda_next, const int*
     bool stereo_composed = false;
     std::vector<double> dfull(ns, 0.);
     for (int a = 0; a < nf; a++) dfull[fidx[a]] = dshared[a];
-    const bool ahead = s->speculate && s->level_accepted[lambda_level(lambda)];
+    const bool ahead = trial_runs_ahead(s, lambda);
     PART_TAKE(npart, s, (size_t)s->nblk64 * 2);
     if (s->ncams == 1) {
         DeltaC dc;
@@ -925,7 +932,7 @@ int be_step_err(void* user, double lambda, double lambda_next, const int* fidx, 
     ccalib_solver::Retry& r = s->retry;
     if (r.inflight) {
         r.inflight = false;
-        const bool ahead_now = s->speculate && s->level_accepted[s->last_level];
+        const bool ahead_now = trial_runs_ahead(s, lambda);
         const bool match = !launched && r.lambda == lambda && r.lambda_next == lambda_next && r.nf == nf && r.cur == cur &&
                            r.t.ahead == ahead_now && (!ahead_now || r.t.lam2 == retry_lambda(s, lambda_next)) &&
                            std::memcmp(dshared, r.dsh, sizeof(double) * nf) == 0 &&
