@@ -102,6 +102,8 @@ struct ccalib_solver {
     unsigned long long seq = 0;
     double wait_limit_s = 120.;         // longest wait for one pass's sums (CCALIB_WAIT_LIMIT_S)
     double t_wait = 0, t_enqueue = 0;  // host seconds spent polling / inside backend calls before polling
+    double t_think = 0, t_launch1 = 0;  // ... between the end of a wait and the next trial's first launch / inside that launch
+    std::chrono::steady_clock::time_point t_wait_end;
     std::chrono::steady_clock::time_point t_enter;
     static constexpr int kRedCap = 4096;
 
@@ -317,8 +319,9 @@ int wait_reduction(ccalib_solver* s, const Pending& p, int n) {
         __builtin_ia32_pause();
     }
     std::atomic_thread_fence(std::memory_order_acquire);
-    s->t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count();
-    s->t_enter = std::chrono::steady_clock::now();
+    s->t_wait_end = std::chrono::steady_clock::now();
+    s->t_wait += std::chrono::duration<double>(s->t_wait_end - tw0).count();
+    s->t_enter = s->t_wait_end;
     if (s->cb) {
         int rc = s->cb(s->cb_user, s->h_red[p.slot], n);
         if (rc) return set_error(CCALIB_ERR_HIP, "all-reduce callback failed (%d)", rc);
@@ -790,6 +793,7 @@ int launch_trial(ccalib_solver* s, double lambda, double lambda_next, const int*
     for (int a = 0; a < nf; a++) dfull[fidx[a]] = dshared[a];
     const bool ahead = trial_runs_ahead(s, lambda);
     PART_TAKE(npart, s, (size_t)s->nblk64 * 2);
+    const auto tl0 = std::chrono::steady_clock::now();
     if (s->ncams == 1) {
         DeltaC dc;
         for (int k = 0; k < I_NMODEL; k++) dc.v[k] = 0;
@@ -818,6 +822,8 @@ int launch_trial(ccalib_solver* s, double lambda, double lambda_next, const int*
         s->pc3_fresh = compose_here;
         stereo_composed = compose_here;
     }
+    s->t_think += std::chrono::duration<double>(tl0 - s->t_wait_end).count();
+    s->t_launch1 += std::chrono::duration<double>(std::chrono::steady_clock::now() - tl0).count();
     if ((rc = queue_colsum(s, npart, s->nblk64, 2, 0))) return rc;
     store_shared(s, shared_new);
     t->ahead = ahead;
@@ -1486,7 +1492,8 @@ int ccalib_solver_run(ccalib_solver* s, int term_type, int max_iter, double eps,
             std::memcpy(smask + 24, s->imask[1], 18);
         }
     }
-    s->t_wait = s->t_enqueue = 0;
+    s->t_wait = s->t_enqueue = s->t_think = s->t_launch1 = 0;
+    s->t_wait_end = std::chrono::steady_clock::now();
     // what the run-ahead needs to know of the driver's plans: its solver and its iteration limit (CvLevMarq::init)
     s->run_solve_method = solve_method;
     s->run_max_iter = (term_type & CCALIB_TERM_COUNT) ? std::min(std::max(max_iter, 1), 1000) : 30;
@@ -1505,8 +1512,11 @@ int ccalib_solver_run(ccalib_solver* s, int term_type, int max_iter, double eps,
         HIP_TRY(hipStreamSynchronize(s->stream));
     }
     if (std::getenv("CCALIB_TIMING") && stats)
-        std::fprintf(stderr, "[ccalib] run: total %.3f ms, enqueue %.3f ms, polling %.3f ms, other host %.3f ms\n", stats->device_ms,
-                     s->t_enqueue * 1e3, s->t_wait * 1e3, stats->device_ms - (s->t_enqueue + s->t_wait) * 1e3);
+        std::fprintf(stderr,
+                     "[ccalib] run: total %.3f ms, enqueue %.3f ms, polling %.3f ms, other host %.3f ms; wait end -> first launch of "
+                     "a trial %.3f ms, that launch %.3f ms (%d trials)\n",
+                     stats->device_ms, s->t_enqueue * 1e3, s->t_wait * 1e3, stats->device_ms - (s->t_enqueue + s->t_wait) * 1e3,
+                     s->t_think * 1e3, s->t_launch1 * 1e3, stats->err_passes);
     return rc;
 }
 
