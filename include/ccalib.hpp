@@ -89,7 +89,8 @@ inline double calibrateCameraRO(const std::vector<std::vector<Point3f>>& objectP
                                           d.data(), nd, rv.data(), tv.data(), flags, criteria.type, criteria.maxCount,
                                           criteria.epsilon, nullptr, &rms, nullptr));
     cameraMatrix = K;
-    distCoeffs = Mat(nd, 1);
+    // prepareDistCoeffs keeps the caller's orientation: a column for an n x 1 input, a row otherwise (empty included)
+    distCoeffs = distCoeffs.cols == 1 ? Mat(nd, 1) : Mat(1, nd);
     distCoeffs.v = d;
     rvecs.assign(n, Mat(3, 1));
     tvecs.assign(n, Mat(3, 1));
@@ -141,7 +142,8 @@ inline double stereoCalibrate(const std::vector<std::vector<Point3f>>& objectPoi
                                           criteria.epsilon, nullptr, nullptr, nullptr, &rms, nullptr));
     cameraMatrix1 = K1, cameraMatrix2 = K2;
     int nd = ccalib_dist_coeffs_out(flags, 1);
-    distCoeffs1 = Mat(1, nd), distCoeffs2 = Mat(1, nd);
+    distCoeffs1 = distCoeffs1.cols == 1 ? Mat(nd, 1) : Mat(1, nd);
+    distCoeffs2 = distCoeffs2.cols == 1 ? Mat(nd, 1) : Mat(1, nd);
     distCoeffs1.v.assign(d1.begin(), d1.begin() + nd);
     distCoeffs2.v.assign(d2.begin(), d2.begin() + nd);
     return rms;

@@ -71,7 +71,9 @@ inline double calibrateCamera(const std::vector<std::vector<cv::Point3f>>& objec
     check(ccalib_calibrate_camera(n, npts.data(), o.data(), m.data(), imageSize.width, imageSize.height, K.ptr<double>(),
                                   D.ptr<double>(), nd, rv.ptr<double>(), tv.ptr<double>(), flags, crit.type, crit.maxCount,
                                   crit.epsilon, nullptr, &rms, nullptr));
-    cameraMatrix = K, distCoeffs = D;
+    // prepareDistCoeffs keeps the caller's orientation: a column for an n x 1 input, a row otherwise (empty included)
+    const bool column = distCoeffs.cols == 1;
+    cameraMatrix = K, distCoeffs = column ? D : D.reshape(1, 1);
     split_poses(rv, tv, rvecs, tvecs);
     return rms;
 }
@@ -110,8 +112,11 @@ inline double stereoCalibrate(const std::vector<std::vector<cv::Point3f>>& objec
                                   R.ptr<double>(), T.ptr<double>(), E.ptr<double>(), F.ptr<double>(), flags, crit.type,
                                   crit.maxCount, crit.epsilon, nullptr, nullptr, nullptr, &rms, nullptr));
     const int nd = ccalib_dist_coeffs_out(flags, 1);
+    const bool column1 = distCoeffs1.cols == 1, column2 = distCoeffs2.cols == 1;  // orientation kept, as above
     cameraMatrix1 = K1, cameraMatrix2 = K2;
     distCoeffs1 = D1.rowRange(0, nd).clone(), distCoeffs2 = D2.rowRange(0, nd).clone();
+    if (!column1) distCoeffs1 = distCoeffs1.reshape(1, 1);
+    if (!column2) distCoeffs2 = distCoeffs2.reshape(1, 1);
     return rms;
 }
 
