@@ -141,6 +141,7 @@ struct ccalib_solver {
     std::vector<double> spec_U, spec_gs, spec_S;
     double spec_err = 0, spec_lambda = 0;
     int steps_since_jac = 0;
+    bool prev_first_accepted = true;  // the iteration before this one accepted its first trial
     // Whether the last trial step taken at each damping level (10^-16 .. 10^16) was accepted: a step is run
     // ahead only at a level whose last trial was accepted, which follows the accept/reject pattern an LM
     // run settles into (e.g. every first trial at 1e-3 rejected, every retry at 1e-2 accepted).
@@ -662,7 +663,10 @@ int be_jac(void* user, const double* shared, double lambda_hint, double* U, doub
     s->t_enter = std::chrono::steady_clock::now();
     (void)hipGetLastError();  // an error another HIP user of this thread left behind is not ours to report
     const int ns = s->ns();
-    if (s->steps_since_jac > 0) s->level_accepted[s->last_level] = true;  // the driver moved on: that step was accepted
+    if (s->steps_since_jac > 0) {  // the driver moved on: that step was accepted
+        s->level_accepted[s->last_level] = true;
+        s->prev_first_accepted = s->steps_since_jac == 1;
+    }
     s->steps_since_jac = 0;
     if (s->spec_valid && std::memcmp(shared, s->spec_shared, sizeof(double) * ns) == 0) {
         // this pass was run ahead by the step that produced the point: adopt its buffer and sums
@@ -757,13 +761,21 @@ int be_reduce(void* user, double lambda, const int* fidx, int nf, double* Ssum, 
         s->have_cached = true;
     }
     if (!(s->have_cached && s->cached_lambda == lambda)) {
+        // A damping nobody prepared sums for: a retry after a rejection.  Rejections come in runs (near the noise
+        // floor the damping climbs many decades inside one iteration), so the sums for the next decade are taken in
+        // the same round trip: one more pass over the blocks against a whole host turn-around if they are needed.
+        const int lv = lambda_level(lambda);
+        const double lambda_up = s->speculate && lv < 32 ? std::exp((lv + 1 - 16) * std::log(10.)) : 0.;
         int rc = enqueue_schur(s, s->cur, lambda, 0, nullptr);
+        if (!rc && lambda_up != 0.) rc = enqueue_schur(s, s->cur, lambda_up, nsum, nullptr);
         if (rc) return rc;
         const double* red;
-        if ((rc = finish_reduction(s, nsum, &red))) return rc;
+        if ((rc = finish_reduction(s, lambda_up != 0. ? 2 * nsum : nsum, &red))) return rc;
         s->cachedS.assign(red, red + nsum);
         s->cached_lambda = lambda;
         s->have_cached = true;
+        s->have_cached2 = lambda_up != 0.;
+        if (lambda_up != 0.) s->cachedS2.assign(red + nsum, red + 2 * nsum), s->cached_lambda2 = lambda_up;
     }
     return map_schur_sums(s, s->cachedS, fidx, nf, Ssum, bsum);
 }
@@ -775,23 +787,31 @@ int be_reduce(void* user, double lambda, const int* fidx, int nf, double* Ssum, 
 
 void be_fixup(void* user, double* shared, double* prev);
 
-// Whether a trial at this damping gets the Jacobian pass of its trial point run ahead (instead of a residual pass):
-// when the last trial at this level was accepted -- and not in the run's last iteration, whose accepted point the
-// driver never asks a Jacobian for.
-bool trial_runs_ahead(const ccalib_solver* s, double lambda) {
-    return s->speculate && s->level_accepted[lambda_level(lambda)] && s->commits < s->run_max_iter;
+// Whether the nth trial of an iteration (1 = the first), at this damping, gets the Jacobian pass of its trial point
+// run ahead instead of a residual pass.  A wrong "yes" wastes a Jacobian pass, a wrong "no" costs a residual pass and a
+// host turn-around, so the guess follows what LM runs are seen to do:
+//   * first trials are accepted iteration after iteration while the damping walks down: yes when the iteration
+//     before accepted its first trial;
+//   * a run that has settled into "first trial rejected, retry one decade up accepted" (the reference's stereo flag
+//     set): the history of the damping level decides -- was the last trial at this level accepted;
+//   * near the noise floor the damping climbs many decades inside one iteration: after two rejections in a row, no;
+//   * never in the run's last iteration, whose accepted point the driver does not ask a Jacobian for.
+bool trial_runs_ahead(const ccalib_solver* s, double lambda, int nth) {
+    if (!s->speculate || s->commits >= s->run_max_iter || nth >= 3) return false;
+    if (nth == 1 && s->prev_first_accepted) return true;
+    return s->level_accepted[lambda_level(lambda)];
 }
 
 // Enqueues a trial step -- back-substitution into s->d_pose_cur, then either the Jacobian pass run ahead or the
 // residual pass -- and submits its reduction.  Does not wait.
 int launch_trial(ccalib_solver* s, double lambda, double lambda_next, const int* fidx, int nf, const double* dshared,
-                 const double* shared_new, ccalib_solver::Trial* t) {
+                 const double* shared_new, int nth, ccalib_solver::Trial* t) {
     int rc;
     const int cur = s->cur, ns = s->ns();
     bool stereo_composed = false;
     std::vector<double> dfull(ns, 0.);
     for (int a = 0; a < nf; a++) dfull[fidx[a]] = dshared[a];
-    const bool ahead = trial_runs_ahead(s, lambda);
+    const bool ahead = trial_runs_ahead(s, lambda, nth);
     PART_TAKE(npart, s, (size_t)s->nblk64 * 2);
     const auto tl0 = std::chrono::steady_clock::now();
     if (s->ncams == 1) {
@@ -857,7 +877,7 @@ int launch_trial(ccalib_solver* s, double lambda, double lambda_next, const int*
     return CCALIB_OK;
 }
 
-// After a trial that the damping history says will be rejected: the driver will then raise the damping one decade
+// After a trial that is expected to be rejected (it got a residual pass only): the driver will then raise the damping one decade
 // and step again from the same Jacobian.  When the Schur sums for that damping are already here (they were taken
 // along with the Jacobian pass), its step can be worked out now -- with the very function the driver uses -- and its
 // kernels put into the stream behind the first trial's, so that the GPU does not idle through a host turn-around
@@ -867,7 +887,6 @@ int launch_retry_ahead(ccalib_solver* s, double lambda, const int* fidx, int nf)
     ccalib_solver::Retry& r = s->retry;
     const int lv = lambda_level(lambda), ns = s->ns();
     if (!s->retry_enabled || !s->speculate || chain_possible(s) || !s->com_valid || s->cb || lv >= 32 || nf > 42) return CCALIB_OK;
-    if (s->level_accepted[lv] || !s->level_accepted[lv + 1]) return CCALIB_OK;  // only the pattern "rejected, then accepted"
     const double lambda2 = std::exp((lv + 1 - 16) * std::log(10.));
     if (!s->have_cached2 || s->cached_lambda2 != lambda2) return CCALIB_OK;
     std::vector<double> Ssum((size_t)nf * nf), bsum(nf);
@@ -882,7 +901,7 @@ int launch_retry_ahead(ccalib_solver* s, double lambda, const int* fidx, int nf)
     const bool was = s->level_accepted[lv];
     s->level_accepted[lv] = false;
     std::swap(s->d_pose_cur, s->d_pose_retry);
-    rc = launch_trial(s, lambda2, lambda, fidx, nf, r.dsh, r.shared, &r.t);
+    rc = launch_trial(s, lambda2, lambda, fidx, nf, r.dsh, r.shared, s->steps_since_jac + 1, &r.t);
     std::swap(s->d_pose_cur, s->d_pose_retry);
     s->level_accepted[lv] = was;
     if (rc) return rc;
@@ -938,7 +957,7 @@ int be_step_err(void* user, double lambda, double lambda_next, const int* fidx, 
     ccalib_solver::Retry& r = s->retry;
     if (r.inflight) {
         r.inflight = false;
-        const bool ahead_now = trial_runs_ahead(s, lambda);
+        const bool ahead_now = trial_runs_ahead(s, lambda, s->steps_since_jac);
         const bool match = !launched && r.lambda == lambda && r.lambda_next == lambda_next && r.nf == nf && r.cur == cur &&
                            r.t.ahead == ahead_now && (!ahead_now || r.t.lam2 == retry_lambda(s, lambda_next)) &&
                            std::memcmp(dshared, r.dsh, sizeof(double) * nf) == 0 &&
@@ -955,7 +974,7 @@ int be_step_err(void* user, double lambda, double lambda_next, const int* fidx, 
         }
     }
     if (!launched) {
-        if ((rc = launch_trial(s, lambda, lambda_next, fidx, nf, dshared, shared_new, &t))) return rc;
+        if ((rc = launch_trial(s, lambda, lambda_next, fidx, nf, dshared, shared_new, s->steps_since_jac, &t))) return rc;
         if (!t.ahead && (rc = launch_retry_ahead(s, lambda, fidx, nf))) return rc;
         if (s->retry.inflight) store_shared(s, shared_new);  // the solver's parameters are this trial's until the driver moves on
     }
@@ -1256,6 +1275,7 @@ int ccalib_solver_set_start(ccalib_solver* s, const double* intr, const unsigned
     s->have_cached2 = false;
     s->spec_valid = false;
     s->steps_since_jac = 0;
+    s->prev_first_accepted = true;
     for (bool& b : s->level_accepted) b = true;
     return CCALIB_OK;
 }
