@@ -310,7 +310,8 @@ def whole_call(pkg, obj, ms):
     pts = ms.img.shape[0] * ms.img.shape[1]
     return {"ms": round(dt * 1e3, 2), "lm_loop_ms": round(got["device_ms"], 2), "iters": got["iters"], "rms_px": got["rms"],
             "points_per_s": pts * got["jac_passes"] / dt,
-            "note": "host buffers in, results out: argument checks, upload, device initialisation, LM loop, download"}
+            "note": "host buffers in, results out: the Python wrapper's flattening of the point arrays (~5 ms here; a C or C++ "
+                    "caller hands over flat arrays), argument checks, upload, device initialisation, LM loop, download"}
 
 
 def opencv_check(pkg, synth):
