@@ -141,7 +141,7 @@ struct ccalib_solver {
     std::vector<double> spec_U, spec_gs, spec_S;
     double spec_err = 0, spec_lambda = 0;
     int steps_since_jac = 0;
-    bool prev_first_accepted = true;  // the iteration before this one accepted its first trial
+    int prev_trials = 1;              // trials the iteration before this one took (1: its first trial was accepted)
     // Whether the last trial step taken at each damping level (10^-16 .. 10^16) was accepted: a step is run
     // ahead only at a level whose last trial was accepted, which follows the accept/reject pattern an LM
     // run settles into (e.g. every first trial at 1e-3 rejected, every retry at 1e-2 accepted).
@@ -665,7 +665,7 @@ int be_jac(void* user, const double* shared, double lambda_hint, double* U, doub
     const int ns = s->ns();
     if (s->steps_since_jac > 0) {  // the driver moved on: that step was accepted
         s->level_accepted[s->last_level] = true;
-        s->prev_first_accepted = s->steps_since_jac == 1;
+        s->prev_trials = s->steps_since_jac;
     }
     s->steps_since_jac = 0;
     if (s->spec_valid && std::memcmp(shared, s->spec_shared, sizeof(double) * ns) == 0) {
@@ -789,17 +789,18 @@ void be_fixup(void* user, double* shared, double* prev);
 
 // Whether the nth trial of an iteration (1 = the first), at this damping, gets the Jacobian pass of its trial point
 // run ahead instead of a residual pass.  A wrong "yes" wastes a Jacobian pass, a wrong "no" costs a residual pass and a
-// host turn-around, so the guess follows what LM runs are seen to do:
-//   * first trials are accepted iteration after iteration while the damping walks down: yes when the iteration
-//     before accepted its first trial;
-//   * a run that has settled into "first trial rejected, retry one decade up accepted" (the reference's stereo flag
-//     set): the history of the damping level decides -- was the last trial at this level accepted;
-//   * near the noise floor the damping climbs many decades inside one iteration: after two rejections in a row, no;
+// host turn-around, so the guess follows what LM runs are seen to do -- they repeat the iteration before:
+//   * first trials are accepted iteration after iteration while the damping walks down: yes for a first trial when
+//     the iteration before accepted its first trial;
+//   * a run settles into "first trial rejected, retry one decade up accepted" (the reference's stereo flag set):
+//     yes for the nth trial when the iteration before was accepted at its nth trial and the last trial at this
+//     damping level was accepted;
+//   * near the noise floor the damping climbs many decades inside one iteration: those retries match neither;
 //   * never in the run's last iteration, whose accepted point the driver does not ask a Jacobian for.
 bool trial_runs_ahead(const ccalib_solver* s, double lambda, int nth) {
-    if (!s->speculate || s->commits >= s->run_max_iter || nth >= 3) return false;
-    if (nth == 1 && s->prev_first_accepted) return true;
-    return s->level_accepted[lambda_level(lambda)];
+    if (!s->speculate || s->commits >= s->run_max_iter) return false;
+    if (nth == 1 && s->prev_trials == 1) return true;
+    return (nth == 1 || s->prev_trials == nth) && s->level_accepted[lambda_level(lambda)];
 }
 
 // Enqueues a trial step -- back-substitution into s->d_pose_cur, then either the Jacobian pass run ahead or the
@@ -1275,7 +1276,7 @@ int ccalib_solver_set_start(ccalib_solver* s, const double* intr, const unsigned
     s->have_cached2 = false;
     s->spec_valid = false;
     s->steps_since_jac = 0;
-    s->prev_first_accepted = true;
+    s->prev_trials = 1;
     for (bool& b : s->level_accepted) b = true;
     return CCALIB_OK;
 }
