@@ -66,6 +66,18 @@ def _flatten(obj_views, img_views):
     return len(npts), npts, obj, img
 
 
+TRACE_FIELDS = ("iter", "lambda_lg10_first", "lambda_lg10_accepted", "trials", "err_prev", "err", "step_norm2", "ms")
+
+
+def last_lm_trace():
+    """Per-iteration records of the last LM run on this thread (ccalib_last_lm_trace): rows of TRACE_FIELDS."""
+    lib = capi.load()
+    n = C.c_int()
+    buf = np.zeros((1000, len(TRACE_FIELDS)))
+    capi.check(lib.ccalib_last_lm_trace(_p(buf), C.c_int(buf.shape[0]), C.byref(n)))
+    return buf[:min(n.value, buf.shape[0])].copy()
+
+
 def calibrate_camera(obj_views, img_views, size, K=None, dist=None, ndist=5, flags=0,
                      criteria=(TERM_COUNT | TERM_EPS, 30, DBL_EPSILON), init_rt=None):
     """cv::calibrateCamera.  Returns dict(rms, K, dist, rvecs, tvecs, iters, jac_passes, err_passes, ...)."""
@@ -280,7 +292,9 @@ class Solver:
         return U, gs, e.value
 
     def fetch_blocks(self):
-        V, W, ge = np.zeros((self.nviews, 6, 6)), np.zeros((self.nviews, 18, 6)), np.zeros((self.nviews, 6))
+        """Per-view V, W, ge of the last Jacobian pass (W rows: 18 intrinsics, or the 42 stereo shared parameters)."""
+        nrow = 18 if self.ncams == 1 else 42
+        V, W, ge = np.zeros((self.nviews, 6, 6)), np.zeros((self.nviews, nrow, 6)), np.zeros((self.nviews, 6))
         capi.check(self._lib.ccalib_solver_fetch_blocks(self._h, _p(V), _p(W), _p(ge)))
         return V, W, ge
 

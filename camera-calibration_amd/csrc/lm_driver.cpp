@@ -151,9 +151,21 @@ void lm_trial_step(int ns, int nf, const int* fidx, const double* U, const doubl
     }
 }
 
+// per-iteration records of the last ccalib_lm_run on this thread (ccalib_last_lm_trace)
+thread_local std::vector<double> g_lm_trace;
+
 }  // namespace ccalib
 
 using namespace ccalib;
+
+extern "C" int ccalib_last_lm_trace(double* records, int cap, int* nrecords) {
+    if (!nrecords || cap < 0 || (cap > 0 && !records)) return set_error(CCALIB_ERR_ARG, "ccalib_last_lm_trace: bad arguments");
+    const int n = (int)(g_lm_trace.size() / CCALIB_TRACE_FIELDS);
+    *nrecords = n;
+    const int m = std::min(n, cap);
+    if (m > 0) std::memcpy(records, g_lm_trace.data(), sizeof(double) * CCALIB_TRACE_FIELDS * m);
+    return CCALIB_OK;
+}
 
 extern "C" int ccalib_lm_run(const ccalib_backend* be, void* user, double* shared, const unsigned char* smask,
                              int term_type, int max_iter, double eps, int solve_method, ccalib_stats* stats) {
@@ -184,6 +196,7 @@ extern "C" int ccalib_lm_run(const ccalib_backend* be, void* user, double* share
         }
     } trace_close{trace};
 
+    g_lm_trace.clear();
     std::vector<int> fidx;
     for (int i = 0; i < ns; i++)
         if (smask[i]) fidx.push_back(i);
@@ -222,6 +235,12 @@ extern "C" int ccalib_lm_run(const ccalib_backend* be, void* user, double* share
             if (++lambdaLg10 > 16) break;
             trials++;
             if ((rc = step_and_eval(errNorm))) return rc;
+        }
+        {
+            const double rec[CCALIB_TRACE_FIELDS] = {(double)iters, (double)lambda_first, (double)std::min(lambdaLg10, 16),
+                                                     (double)trials, prevErrNorm, errNorm, dn2,
+                                                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ti).count()};
+            if (g_lm_trace.size() < (size_t)CCALIB_TRACE_FIELDS * 1000) g_lm_trace.insert(g_lm_trace.end(), rec, rec + CCALIB_TRACE_FIELDS);
         }
         if (trace)
             std::fprintf(trace,

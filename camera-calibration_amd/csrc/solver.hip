@@ -1597,9 +1597,35 @@ int ccalib_solver_eval_jacobian(ccalib_solver* s, double* U, double* gs, double*
 }
 
 int ccalib_solver_fetch_blocks(ccalib_solver* s, double* V, double* W, double* ge) {
-    if (!s || !s->started || s->ncams != 1) return set_error(CCALIB_ERR_STATE, "fetch_blocks: mono solver after a Jacobian pass");
+    if (!s || !s->started || !V || !W || !ge) return set_error(CCALIB_ERR_STATE, "fetch_blocks: a started solver and three outputs needed");
     HIP_TRY(hipSetDevice(s->device));
     const ModelOps* m = s->ops[0];
+    if (s->ncams == 2) {
+        // the view systems as the stereo elimination kernels assemble them from both cameras' blocks
+        const int kc = s->kcols(), ns = 42;
+        const size_t n = s->nviews;
+        double* d = nullptr;
+        HIP_TRY(hipMalloc(&d, sizeof(double) * n * (36 + 6 + (size_t)kc * 6)));
+        double *dV = d, *dge = d + n * 36, *dW = d + n * 42;
+        std::vector<double> hW(n * kc * 6);
+        hipError_t e = hipSuccess;
+        if (!launch_stereo_fetch(m->NC, s->d_blk[0][s->cur], s->d_blk[1][s->cur], s->d_cmp[s->cur], s->lr_jac[s->cur], s->npad,
+                                 s->nviews, dV, dW, dge, s->stream))
+            e = hipErrorInvalidValue;
+        if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+        if (e == hipSuccess) e = hipMemcpy(V, dV, sizeof(double) * n * 36, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(ge, dge, sizeof(double) * n * 6, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(hW.data(), dW, sizeof(double) * hW.size(), hipMemcpyDeviceToHost);
+        (void)hipFree(d);
+        HIP_TRY(e);
+        std::memset(W, 0, sizeof(double) * n * ns * 6);
+        for (size_t v = 0; v < n; v++)
+            for (int k = 0; k < kc; k++) {
+                const int row = k < 6 ? k : k < 6 + m->NC ? 6 + m->col(k - 6) : 24 + s->ops[1]->col(k - 6 - m->NC);
+                std::memcpy(W + (v * ns + row) * 6, hW.data() + (v * kc + k) * 6, 6 * sizeof(double));
+            }
+        return CCALIB_OK;
+    }
     std::vector<double> h((size_t)m->NBLK * s->npad);
     HIP_TRY(hipStreamSynchronize(s->stream));
     HIP_TRY(hipMemcpy(h.data(), s->d_blk[0][s->cur], sizeof(double) * h.size(), hipMemcpyDeviceToHost));

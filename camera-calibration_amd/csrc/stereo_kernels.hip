@@ -748,6 +748,38 @@ __global__ __launch_bounds__(64) void k_stereo_backsub(const double* blk0, const
     }
 }
 
+// The stereo view system as the elimination kernels assemble it, written out for inspection: per view
+// V = V0 + A^T V3 A (36, full), ge = ge0 + A^T ge3 (6), and the coupling rows W (6 + 2 NC rows of 6, kernel column order:
+// W_LR = B^T V3 A, camera 0's W0, camera 1's W3 A).  Same device functions as k_stereo_backsub.
+template <int NC>
+__global__ __launch_bounds__(64) void k_stereo_fetch(const double* blk0, const double* blk1, const double* cmp, StereoLR lr,
+                                                     int npad, int nviews, double* V, double* W, double* ge) {
+    constexpr int NB = 27 + 6 * NC, KC = 6 + 2 * NC;
+    const int v = blockIdx.x * 64 + threadIdx.x;
+    if (v >= nviews) return;
+    Cmp c;
+    load_cmp(cmp, npad, v, lr, c);
+    ViewSys s;
+    assemble_view<NC, NC>(blk0, blk1, npad, v, c, s);
+    for (int a = 0; a < 6; a++)
+        for (int b = a; b < 6; b++) V[(size_t)v * 36 + a * 6 + b] = V[(size_t)v * 36 + b * 6 + a] = s.Vu[tri6(a, b)];
+    for (int a = 0; a < 6; a++) ge[(size_t)v * 6 + a] = s.ge[a];
+    double WLR[6][6];
+    Bt_times(c, s.M, WLR);
+    double* Wv = W + (size_t)v * KC * 6;
+    for (int a = 0; a < 6; a++)
+        for (int b = 0; b < 6; b++) Wv[a * 6 + b] = WLR[a][b];
+    for (int i = 0; i < NC; i++) {
+        double w3[6], wa[6];
+        for (int b = 0; b < 6; b++) {
+            Wv[(6 + i) * 6 + b] = blk0[blk_index(NB, 27 + 6 * i + b, v)];
+            w3[b] = blk1[blk_index(NB, 27 + 6 * i + b, v)];
+        }
+        row_times_A(c, w3, wa);
+        for (int b = 0; b < 6; b++) Wv[(6 + NC + i) * 6 + b] = wa[b];
+    }
+}
+
 }  // namespace
 
 void launch_compose(const double* pose1, const StereoLR& lr, int nviews, int npad, double* pose3, double* cmp, double* pc3,
@@ -779,6 +811,19 @@ static void backsub_t(dim3 grid, hipStream_t st, const double* blk0, const doubl
         case 12: F<12>(__VA_ARGS__); break;  \
         default: return false;               \
     }
+
+template <int NC>
+static void fetch_t(dim3 grid, hipStream_t st, const double* blk0, const double* blk1, const double* cmp, const StereoLR& lr,
+                    int npad, int nviews, double* V, double* W, double* ge) {
+    hipLaunchKernelGGL(k_stereo_fetch<NC>, grid, dim3(64), 0, st, blk0, blk1, cmp, lr, npad, nviews, V, W, ge);
+}
+
+bool launch_stereo_fetch(int nc, const double* blk0, const double* blk1, const double* cmp, const StereoLR& lr, int npad,
+                         int nviews, double* V, double* W, double* ge, hipStream_t st) {
+    dim3 grid((nviews + 63) / 64);
+    CCALIB_FOR_NC(nc, fetch_t, grid, st, blk0, blk1, cmp, lr, npad, nviews, V, W, ge);
+    return true;
+}
 
 bool launch_stereo_lr_sums(int nc, const double* blk1, const double* cmp, const StereoLR& lr, int npad, int nviews,
                            double* part, hipStream_t st) {

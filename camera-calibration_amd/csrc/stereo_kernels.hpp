@@ -69,4 +69,9 @@ bool launch_stereo_backsub(int nc, const double* blk0, const double* blk1, const
                            const StereoLR& lr_new, double* pose3, double* pc3,  // pose3 != null: camera 1's trial poses
                            hipStream_t st);                                       // for the relative pose lr_new as well
 
+// The assembled stereo view systems of a Jacobian pass, for inspection (tests): V nviews x 36, ge nviews x 6,
+// W nviews x (6 + 2 nc) x 6 in kernel column order [om_LR T_LR | camera 0 | camera 1], all device pointers.
+bool launch_stereo_fetch(int nc, const double* blk0, const double* blk1, const double* cmp, const StereoLR& lr, int npad,
+                         int nviews, double* V, double* W, double* ge, hipStream_t st);
+
 }  // namespace ccalib

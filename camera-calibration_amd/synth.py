@@ -244,7 +244,7 @@ def _views_for(obj, view_ids, seed, cam, width, height, depth, margin=4.0, max_a
         px = project(obj, r, t, cam)
         Xc = np.einsum("nij,pj->npi", R, obj.astype(np.float64)) + t[:, None, :]
         ok = ((px[..., 0] >= margin) & (px[..., 0] <= width - 1 - margin) & (px[..., 1] >= margin) &
-              (px[..., 1] <= height - 1 - margin) & (Xc[..., 2] > 50.0)).all(1)
+              (px[..., 1] <= height - 1 - margin) & (Xc[..., 2] > min(50.0, 0.125 * depth[0]))).all(1)
         rvec[todo[ok]] = r[ok]
         tvec[todo[ok]] = t[ok]
         todo = todo[~ok]

@@ -281,7 +281,10 @@ int ccalib_solver_get(ccalib_solver* s, double* intr, double* rt, double* lr, do
  *   eval_error     sum of squared residuals at the current parameters
  *   eval_jacobian  fills the per-view blocks in HBM; returns the shared block U (ns x ns, upper
  *                  triangle, ns = number of free shared parameters), its gradient gs and err
- *   fetch_blocks   copies per-view V (nviews x 36), W (nviews x ns x 6), ge (nviews x 6) to host
+ *   fetch_blocks   copies per-view V (nviews x 36), W (nviews x 18 x 6), ge (nviews x 6) to host.  Stereo solver: the
+ *                  view systems after cvStereoCalibrateImpl's rewrite of camera 1's rows (binocular_chessboard.cpp:
+ *                  152-162), V = both cameras' pose block, W nviews x 42 x 6 with rows [om_LR T_LR | intrinsics of
+ *                  camera 0 | of camera 1] (always 42 rows, also under CCALIB_STEREO_FIX_INTRINSIC)
  *   reduce         Schur sums for damping lambda: Ssum = sum_i W_i V_i'^-1 W_i^T (ns x ns),
  *                  bsum = sum_i W_i V_i'^-1 ge_i
  *   time_kernels   launches each per-point kernel of camera 0 `reps` times back to back and returns
@@ -327,6 +330,18 @@ typedef struct {
 } ccalib_backend;
 int ccalib_lm_run(const ccalib_backend* be, void* user, double* shared, const unsigned char* smask,
                   int term_type, int max_iter, double eps, int solve_method, ccalib_stats* stats);
+
+/*
+ * Per-iteration record of the last ccalib_lm_run on the calling thread (hence of the last ccalib_solver_run,
+ * ccalib_calibrate_camera or ccalib_stereo_calibrate): what CvLevMarq did, iteration by iteration, so that a run can be
+ * compared with another implementation of the same state machine trial for trial.  CCALIB_TRACE_FIELDS doubles per
+ * finished iteration: iteration number, damping exponent (lambdaLg10) of the first trial step, exponent of the accepted
+ * one, number of trial steps, residual sum at the committed point, residual sum at the accepted point, squared norm of
+ * the accepted pose update, host milliseconds.  Copies min(cap, n) records; *nrecords = n (at most 1000 are kept).
+ * The same fields go to the file named by the environment variable CCALIB_TRACE, one JSON line per iteration.
+ */
+enum { CCALIB_TRACE_FIELDS = 8 };
+int ccalib_last_lm_trace(double* records, int cap, int* nrecords);
 
 #ifdef __cplusplus
 }

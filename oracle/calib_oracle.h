@@ -80,6 +80,17 @@ enum { ORC_VARIANT_PP_HALF_SIZE = 1, ORC_VARIANT_SAME_FOCAL_MASK = 2 };
 extern int orc_variants;
 void orc_set_variants(int bits);
 
+/*
+ * Per-iteration record of the LM run inside the next orc_calibrate_camera / orc_stereo_calibrate call: ORC_TRACE_FIELDS
+ * doubles per finished iteration -- iteration number, damping exponent (lambdaLg10) of the first trial, exponent of
+ * the accepted trial, number of trial steps, residual sum at the committed point, residual sum at the accepted
+ * point.  buf holds cap records; NULL switches the record off.  orc_trace_count() = records written by the last run.
+ * (A stereo call without an intrinsic guess calibrates each camera first; the record is that of the stereo loop.)
+ */
+enum { ORC_TRACE_FIELDS = 6 };
+void orc_set_trace(double* buf, int cap);
+int orc_trace_count(void);
+
 /* ---- geometry ---------------------------------------------------------- */
 /* cvRodrigues2, vector -> matrix.  J (may be NULL) is 3x9: J[i*9+k] = dR[k]/dr[i]. */
 void orc_rodrigues_v2m(const double r[3], double R[9], double J[27]);
@@ -163,6 +174,18 @@ double orc_mono_blocks(int nviews, const int* npts, const double* obj, const dou
                        const double intr[18], double aspect, const double* rt, int nfree,
                        const int* free_idx, double* U, double* gc, double* V, double* W,
                        double* ge);
+
+/* The same for the stereo system: one Jacobian pass of cvStereoCalibrateImpl at the given intrinsics (A, 14
+ * coefficients per camera), camera-0 poses rt (nviews x 6) and relative pose lr (6), under `flags` (the ties
+ * CALIB_FIX_ASPECT_RATIO and CALIB_SAME_FOCAL_LENGTH are applied before the pass, as in the loop).  The shared
+ * block is ns = 42 wide: [om_LR T_LR | 18 intrinsics of camera 0 | 18 of camera 1], every intrinsic column kept.
+ *   U  42 x 42, filled where OpenCV fills JtJ (diagonal blocks in full, the blocks above the diagonal), gs 42,
+ *   per view: V 6 x 6 (the pose block after both cameras), W 42 x 6, ge 6.
+ * Returns the sum of squared residuals over both cameras. */
+double orc_stereo_blocks(int nviews, const int* npts, const double* obj, const double* img1, const double* img2,
+                         const double A1[9], const double dist1[14], const double A2[9], const double dist2[14],
+                         int flags, const double* rt, const double* lr, double* U, double* gs, double* V, double* W,
+                         double* ge);
 
 #ifdef __cplusplus
 }

@@ -55,11 +55,34 @@ def lib():
         _LIB.orc_stereo_calibrate.restype = C.c_double
         _LIB.orc_reprojection_error.restype = C.c_double
         _LIB.orc_mono_blocks.restype = C.c_double
+        _LIB.orc_trace_count.restype = C.c_int
+        _LIB.orc_stereo_blocks.restype = C.c_double
     return _LIB
 
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+TRACE_FIELDS = ("iter", "lambda_lg10_first", "lambda_lg10_accepted", "trials", "err_prev", "err")
+
+
+class _Trace:
+    """Per-iteration record of the LM run inside one calibrate call (orc_set_trace): rows of TRACE_FIELDS."""
+
+    def __init__(self, on, cap=1024):
+        self.buf = np.zeros((cap, len(TRACE_FIELDS))) if on else None
+
+    def __enter__(self):
+        if self.buf is not None:
+            lib().orc_set_trace(_p(self.buf), C.c_int(self.buf.shape[0]))
+        return self
+
+    def __exit__(self, *exc):
+        if self.buf is not None:
+            self.rows = self.buf[:lib().orc_trace_count()].copy()
+            lib().orc_set_trace(None, C.c_int(0))
+        return False
 
 
 def _d(a):
@@ -146,8 +169,8 @@ def find_extrinsic(obj, img, A, k14):
 
 def calibrate_camera(obj_views, img_views, size, K=None, dist=None, ndist=5, flags=0,
                      criteria=(TERM_COUNT | TERM_EPS, 30, np.finfo(np.float64).eps), init_rt=None,
-                     schur=True, solve=-1, nthreads=1):
-    """Returns dict(rms, K, dist, rvecs, tvecs, iters, jac_passes, err_passes, lambda_lg10)."""
+                     schur=True, solve=-1, nthreads=1, trace=False):
+    """Returns dict(rms, K, dist, rvecs, tvecs, iters, jac_passes, err_passes, lambda_lg10[, trace])."""
     N, npts, obj, img = _flatten(obj_views, img_views)
     A = np.eye(3).reshape(-1) if K is None else _d(K).reshape(-1).copy()
     d = np.zeros(ndist)
@@ -157,19 +180,23 @@ def calibrate_camera(obj_views, img_views, size, K=None, dist=None, ndist=5, fla
     rv, tv = np.zeros((N, 3)), np.zeros((N, 3))
     st = Stats()
     irt = None if init_rt is None else _d(init_rt).reshape(N, 6)
-    rms = lib().orc_calibrate_camera(C.c_int(N), _p(npts), _p(obj), _p(img), C.c_int(size[0]), C.c_int(size[1]),
-                                     _p(A), _p(d), C.c_int(ndist), _p(rv), _p(tv), C.c_int(flags),
-                                     C.c_int(criteria[0]), C.c_int(criteria[1]), C.c_double(criteria[2]),
-                                     _p(irt), C.c_int(1 if schur else 0), C.c_int(solve), C.c_int(nthreads),
-                                     C.byref(st))
-    return dict(rms=rms, K=A.reshape(3, 3), dist=d, rvecs=rv, tvecs=tv, iters=st.iters,
-                jac_passes=st.jac_passes, err_passes=st.err_passes, lambda_lg10=st.lambda_lg10,
-                final_err=st.final_err)
+    with _Trace(trace) as tr:
+        rms = lib().orc_calibrate_camera(C.c_int(N), _p(npts), _p(obj), _p(img), C.c_int(size[0]), C.c_int(size[1]),
+                                         _p(A), _p(d), C.c_int(ndist), _p(rv), _p(tv), C.c_int(flags),
+                                         C.c_int(criteria[0]), C.c_int(criteria[1]), C.c_double(criteria[2]),
+                                         _p(irt), C.c_int(1 if schur else 0), C.c_int(solve), C.c_int(nthreads),
+                                         C.byref(st))
+    out = dict(rms=rms, K=A.reshape(3, 3), dist=d, rvecs=rv, tvecs=tv, iters=st.iters,
+               jac_passes=st.jac_passes, err_passes=st.err_passes, lambda_lg10=st.lambda_lg10,
+               final_err=st.final_err)
+    if trace:
+        out["trace"] = tr.rows
+    return out
 
 
 def stereo_calibrate(obj_views, img1, img2, K1, d1, K2, d2, size, flags,
                      criteria=(TERM_COUNT | TERM_EPS, 30, 1e-6), init_rt=None, init_lr=None, schur=True,
-                     nthreads=1):
+                     nthreads=1, trace=False):
     N, npts, obj, i1 = _flatten(obj_views, img1)
     _, _, _, i2 = _flatten(obj_views, img2)
     A1, A2 = _d(K1).reshape(-1).copy(), _d(K2).reshape(-1).copy()
@@ -183,14 +210,18 @@ def stereo_calibrate(obj_views, img1, img2, K1, d1, K2, d2, size, flags,
     st = Stats()
     irt = None if init_rt is None else _d(init_rt).reshape(N, 6)
     ilr = None if init_lr is None else _d(init_lr).reshape(6)
-    rms = lib().orc_stereo_calibrate(C.c_int(N), _p(npts), _p(obj), _p(i1), _p(i2), _p(A1), _p(D1), _p(A2), _p(D2),
-                                     C.c_int(size[0]), C.c_int(size[1]), _p(R), _p(T), _p(E), _p(F), C.c_int(flags),
-                                     C.c_int(criteria[0]), C.c_int(criteria[1]), C.c_double(criteria[2]),
-                                     _p(irt), _p(ilr), _p(rt), C.c_int(1 if schur else 0), C.c_int(nthreads),
-                                     C.byref(st))
-    return dict(rms=rms, K1=A1.reshape(3, 3), d1=D1, K2=A2.reshape(3, 3), d2=D2, R=R.reshape(3, 3), T=T,
-                E=E.reshape(3, 3), F=F.reshape(3, 3), rt=rt, iters=st.iters, jac_passes=st.jac_passes,
-                err_passes=st.err_passes, lambda_lg10=st.lambda_lg10, final_err=st.final_err)
+    with _Trace(trace) as tr:
+        rms = lib().orc_stereo_calibrate(C.c_int(N), _p(npts), _p(obj), _p(i1), _p(i2), _p(A1), _p(D1), _p(A2), _p(D2),
+                                         C.c_int(size[0]), C.c_int(size[1]), _p(R), _p(T), _p(E), _p(F), C.c_int(flags),
+                                         C.c_int(criteria[0]), C.c_int(criteria[1]), C.c_double(criteria[2]),
+                                         _p(irt), _p(ilr), _p(rt), C.c_int(1 if schur else 0), C.c_int(nthreads),
+                                         C.byref(st))
+    out = dict(rms=rms, K1=A1.reshape(3, 3), d1=D1, K2=A2.reshape(3, 3), d2=D2, R=R.reshape(3, 3), T=T,
+               E=E.reshape(3, 3), F=F.reshape(3, 3), rt=rt, iters=st.iters, jac_passes=st.jac_passes,
+               err_passes=st.err_passes, lambda_lg10=st.lambda_lg10, final_err=st.final_err)
+    if trace:
+        out["trace"] = tr.rows
+    return out
 
 
 def reprojection_error(obj_views, img_views, K, dist, rvecs, tvecs):
@@ -212,3 +243,19 @@ def mono_blocks(obj_views, img_views, intr18, aspect, rt, free_idx):
     err = lib().orc_mono_blocks(C.c_int(N), _p(npts), _p(obj), _p(img), _p(_d(intr18)), C.c_double(aspect),
                                 _p(_d(rt).reshape(N, 6)), C.c_int(c), _p(fi), _p(U), _p(gc), _p(V), _p(W), _p(ge))
     return dict(err=err, U=U, gc=gc, V=V, W=W, ge=ge)
+
+
+def stereo_blocks(obj_views, img1, img2, K1, d1, K2, d2, flags, rt, lr):
+    """The stereo normal equations of one Jacobian pass at fixed parameters (see calib_oracle.h): dict(err, U 42x42
+    (upper block triangle), gs 42, V Nx6x6, W Nx42x6, ge Nx6); shared order [om_LR T_LR | intr cam 0 | intr cam 1]."""
+    N, npts, obj, i1 = _flatten(obj_views, img1)
+    _, _, _, i2 = _flatten(obj_views, img2)
+    D1, D2 = np.zeros(14), np.zeros(14)
+    D1[:np.size(d1)] = np.ravel(d1)
+    D2[:np.size(d2)] = np.ravel(d2)
+    U, gs = np.zeros((42, 42)), np.zeros(42)
+    V, W, ge = np.zeros((N, 6, 6)), np.zeros((N, 42, 6)), np.zeros((N, 6))
+    err = lib().orc_stereo_blocks(C.c_int(N), _p(npts), _p(obj), _p(i1), _p(i2), _p(_d(K1).reshape(-1)), _p(D1),
+                                  _p(_d(K2).reshape(-1)), _p(D2), C.c_int(flags), _p(_d(rt).reshape(N, 6)),
+                                  _p(_d(lr).reshape(6)), _p(U), _p(gs), _p(V), _p(W), _p(ge))
+    return dict(err=err, U=U, gs=gs, V=V, W=W, ge=ge)

@@ -32,6 +32,12 @@
 int orc_variants = 0;
 void orc_set_variants(int bits) { orc_variants = bits; }
 
+static double* g_trace = 0;
+static int g_trace_cap = 0, g_trace_n = 0;
+void orc_set_trace(double* buf, int cap) { g_trace = buf, g_trace_cap = buf ? cap : 0, g_trace_n = 0; }
+int orc_trace_count(void) { return g_trace_n; }
+static void trace_attach(orc_levmarq* lm) { lm->trace = g_trace, lm->trace_cap = g_trace_cap, lm->trace_n = 0; }
+
 /* ---- per-view 6x6 elimination shared by the mono and stereo schur paths ---------------- */
 
 typedef struct {
@@ -267,6 +273,7 @@ double orc_calibrate_camera(int nviews, const int* npts, const double* obj_in, c
 
     orc_levmarq lm;
     orc_lm_init(&lm, nparams, 0, term_type, max_iter, eps, !schur);
+    trace_attach(&lm);
     if (flags & ORC_USE_LU) lm.solveMethod = ORC_SOLVE_LU;
     if (solve_override >= 0) lm.solveMethod = solve_override;
     lm.param[0] = A[0], lm.param[1] = A[4], lm.param[2] = A[2], lm.param[3] = A[5];
@@ -406,6 +413,7 @@ double orc_calibrate_camera(int nviews, const int* npts, const double* obj_in, c
         stats->lambda_lg10 = lm.lambdaLg10;
         stats->final_err = reprojErr;
     }
+    g_trace_n = lm.trace_n;
     if (schur) schur_free(&ss);
     free(scratch), free(Uacc), free(ofs), free(obj);
     orc_lm_free(&lm);
@@ -481,6 +489,12 @@ double orc_mono_blocks(int nviews, const int* npts, const double* obj, const dou
 
 /* ---- stereo ---------------------------------------------------------------------------- */
 
+/* orc_stereo_blocks: when armed, the Schur-path loop below hands out the system of its first Jacobian pass and stops */
+static struct {
+    int armed;
+    double *U, *gs, *V, *W, *ge, *err;
+} g_capture;
+
 static int dbl_cmp(const void* a, const void* b) {
     double x = *(const double*)a, y = *(const double*)b;
     return (x > y) - (x < y);
@@ -533,6 +547,7 @@ double orc_stereo_calibrate(int nviews, const int* npts, const double* obj, cons
 
     orc_levmarq lm;
     orc_lm_init(&lm, nparams, 0, term_type, max_iter, eps, !schur);
+    trace_attach(&lm);
     if (flags & ORC_USE_LU) lm.solveMethod = ORC_SOLVE_LU;
 
     if (recomputeIntrinsics) {
@@ -802,6 +817,16 @@ double orc_stereo_calibrate(int nviews, const int* npts, const double* obj, cons
             }
         }
         if (wantErr) lm.errNorm = reprojErr;
+        if (calcJ && schur && g_capture.armed) {
+            g_capture.armed = 0;
+            memcpy(g_capture.U, ss.U, sizeof(double) * ns * ns);
+            memcpy(g_capture.gs, ss.gs, sizeof(double) * ns);
+            memcpy(g_capture.V, ss.V, sizeof(double) * (size_t)nviews * 36);
+            memcpy(g_capture.W, ss.W, sizeof(double) * (size_t)nviews * ns * 6);
+            memcpy(g_capture.ge, ss.ge, sizeof(double) * (size_t)nviews * 6);
+            *g_capture.err = reprojErr;
+            break;
+        }
     }
 
     double R_LR[9];
@@ -838,8 +863,25 @@ double orc_stereo_calibrate(int nviews, const int* npts, const double* obj, cons
         stats->lambda_lg10 = lm.lambdaLg10;
         stats->final_err = reprojErr;
     }
+    g_trace_n = lm.trace_n;
     if (schur) schur_free(&ss);
     free(scratch), free(Uacc), free(vofs);
     orc_lm_free(&lm);
     return sqrt(reprojErr / (pointsTotal * 2));
+}
+
+double orc_stereo_blocks(int nviews, const int* npts, const double* obj, const double* img1, const double* img2,
+                         const double A1[9], const double dist1[14], const double A2[9], const double dist2[14],
+                         int flags, const double* rt, const double* lr, double* U, double* gs, double* V, double* W,
+                         double* ge) {
+    double a1[9], a2[9], d1[14], d2[14], R[9], T[3], err = -1;
+    memcpy(a1, A1, sizeof(a1)), memcpy(a2, A2, sizeof(a2));
+    memcpy(d1, dist1, sizeof(d1)), memcpy(d2, dist2, sizeof(d2));
+    flags = (flags | ORC_USE_INTRINSIC_GUESS) & ~ORC_FIX_INTRINSIC;
+    g_capture.armed = 1;
+    g_capture.U = U, g_capture.gs = gs, g_capture.V = V, g_capture.W = W, g_capture.ge = ge, g_capture.err = &err;
+    orc_stereo_calibrate(nviews, npts, obj, img1, img2, a1, d1, a2, d2, 0, 0, R, T, 0, 0, flags, ORC_TERM_COUNT, 1, 0., rt, lr,
+                         0, 1, 1, 0);
+    g_capture.armed = 0;
+    return err;
 }

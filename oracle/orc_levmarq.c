@@ -43,6 +43,20 @@ void orc_lm_init(orc_levmarq* lm, int nparams, int nerrs, int term_type, int max
     lm->solveMethod = ORC_SOLVE_SVD;
 }
 
+/* One record per finished iteration, the fields the product's driver reports for its own runs:
+ * iteration, damping exponent of the first trial, exponent of the accepted trial, number of trials,
+ * residual sum at the committed point, residual sum at the accepted point. */
+static void lm_trace_record(orc_levmarq* lm) {
+    if (!lm->trace || lm->trace_n >= lm->trace_cap) return;
+    double* r = lm->trace + (size_t)ORC_TRACE_FIELDS * lm->trace_n++;
+    r[0] = lm->iters;
+    r[1] = lm->tr_first;
+    r[2] = lm->lambdaLg10 < 16 ? lm->lambdaLg10 : 16;
+    r[3] = lm->tr_trials;
+    r[4] = lm->prevErrNorm;
+    r[5] = lm->errNorm;
+}
+
 void orc_lm_free(orc_levmarq* lm) {
     free(lm->mask);
     free(lm->param);
@@ -107,6 +121,7 @@ int orc_lm_update_alt(orc_levmarq* lm, int* want_J, int* want_err) {
     }
     if (lm->state == ORC_LM_CALC_J) {
         memcpy(lm->prevParam, lm->param, sizeof(double) * lm->nparams);
+        lm->tr_first = lm->lambdaLg10, lm->tr_trials = 1;
         lm_step(lm);
         lm->prevErrNorm = lm->errNorm;
         lm->errNorm = 0;
@@ -117,6 +132,7 @@ int orc_lm_update_alt(orc_levmarq* lm, int* want_J, int* want_err) {
     /* CHECK_ERR */
     if (lm->errNorm > lm->prevErrNorm) {
         if (++lm->lambdaLg10 <= 16) {
+            lm->tr_trials++;
             lm_step(lm);
             lm->errNorm = 0;
             *want_err = 1;
@@ -124,6 +140,7 @@ int orc_lm_update_alt(orc_levmarq* lm, int* want_J, int* want_err) {
             return 1;
         }
     }
+    lm_trace_record(lm);
     lm->lambdaLg10 = lm->lambdaLg10 - 1 > -16 ? lm->lambdaLg10 - 1 : -16;
     if (++lm->iters >= lm->max_iter ||
         rel_l2(lm->param, lm->prevParam, lm->nparams) < lm->epsilon) {

@@ -22,6 +22,9 @@ typedef struct orc_levmarq {
     int solveMethod;
     orc_step_fn custom_step;
     void* user;
+    /* optional per-iteration record (orc_set_trace): see calib_oracle.h */
+    double* trace;
+    int trace_cap, trace_n, tr_first, tr_trials;
 } orc_levmarq;
 
 /* dense != 0 allocates JtJ/JtErr; nerrs > 0 allocates J/err. */

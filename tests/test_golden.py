@@ -9,7 +9,8 @@ import numpy as np
 import pytest
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-MONO = ["mono_9x6_20views", "mono_8x5_aspect_lu", "mono_circles_30views"]
+MONO = ["mono_9x6_20views", "mono_8x5_aspect_lu", "mono_circles_30views", "mono_circles_4x11_ref"]
+STEREO = ["stereo_9x6_16pairs", "stereo_circles_4x11_ref"]
 REL = 1e-6
 
 
@@ -28,7 +29,13 @@ def _mono_args(g):
 def _check_mono(got, g, pose_tol):
     assert abs(got["rms"] - float(g["rms"])) <= REL * float(g["rms"])
     assert np.allclose(got["K"], g["K"], rtol=REL, atol=1e-9)
-    assert np.allclose(got["dist"], g["dist"], rtol=1e-5, atol=1e-8)
+    # distortion: 1e-6 relative, element by element -- unless the minimum itself does not determine the coefficients
+    # that well: the file holds the oracle's own dense-vs-Schur spread on this input, and where four times that
+    # exceeds 1e-6 (the 88-point circle grid: 1.2e-6, on p2 = 2.5e-4) it is the bound.  The absolute floor of 1e-9
+    # (a millionth of a pixel at this focal length) is for coefficients that happen to come out near zero.
+    dtol = max(REL, 4 * float(g["dist_spread"]))
+    assert dtol <= 5e-6, dtol
+    assert np.allclose(got["dist"], g["dist"], rtol=dtol, atol=1e-9)
     assert np.abs(got["rvecs"] - g["rvecs"]).max() < pose_tol
     assert np.abs(got["tvecs"] - g["tvecs"]).max() < pose_tol * max(1.0, np.abs(g["tvecs"]).max())
     # +-1 where the criteria stop the run on a meaningful step size.  With eps = DBL_EPSILON (cv::calibrateCamera's
@@ -48,8 +55,9 @@ def test_oracle_reproduces_golden_mono(orc, name):
     _check_mono(schur, g, 1e-7)
 
 
-def test_oracle_reproduces_golden_stereo(orc):
-    g = _load("stereo_9x6_16pairs")
+@pytest.mark.parametrize("name", STEREO)
+def test_oracle_reproduces_golden_stereo(orc, name):
+    g = _load(name)
     size = tuple(int(x) for x in g["size"])
     crit = (int(g["criteria"][0]), int(g["criteria"][1]), float(g["criteria"][2]))
     for schur in (False, True):
@@ -74,8 +82,9 @@ def test_hip_matches_golden_mono(pkg, name):
 
 
 @pytest.mark.gpu
-def test_hip_matches_golden_stereo(pkg):
-    g = _load("stereo_9x6_16pairs")
+@pytest.mark.parametrize("name", STEREO)
+def test_hip_matches_golden_stereo(pkg, name):
+    g = _load(name)
     size = tuple(int(x) for x in g["size"])
     crit = (int(g["criteria"][0]), int(g["criteria"][1]), float(g["criteria"][2]))
     K1 = pkg.init_camera_matrix_2d(g["obj"], g["img1"], size)
