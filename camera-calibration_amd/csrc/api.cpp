@@ -196,6 +196,8 @@ int ccalib_stereo_calibrate(int nviews, const int* npts, const float* obj_xyz, c
         return set_error(CCALIB_ERR_ARG, "stereoCalibrate: null argument");
     int rc = check_model_flags(flags);
     if (rc) return rc;
+    if ((init_rt == nullptr) != (init_lr == nullptr))
+        return set_error(CCALIB_ERR_ARG, "stereoCalibrate: init_rt and init_lr must be given together or not at all");
     size_t total = 0;
     for (int i = 0; i < nviews; i++) {
         if (npts[i] < 4) return set_error(CCALIB_ERR_ARG, "view %d has %d points (at least 4 needed)", i, npts[i]);
@@ -255,8 +257,6 @@ int ccalib_stereo_calibrate(int nviews, const int* npts, const float* obj_xyz, c
     bool shared = views_share_board(nviews, npts, obj_xyz);
     SolverGuard g;
     if ((rc = ccalib_solver_create(&g.s, 0, 2, nviews, npts, obj_xyz, shared ? 1 : 0, img1_uv, img2_uv))) return rc;
-    if ((init_rt == nullptr) != (init_lr == nullptr))
-        return set_error(CCALIB_ERR_ARG, "stereoCalibrate: init_rt and init_lr must be given together or not at all");
     double lr[6];
     const bool given = init_rt && init_lr;
     if (given) {

@@ -22,10 +22,6 @@
 //   * k_colsum      every column sum of a pass in one launch, written where the host polls.
 // Reductions are fixed-order trees (no atomics on data), so results are bitwise reproducible.
 #include "kernels.hpp"
-#ifndef CCALIB_JF_ABLATE
-#define CCALIB_JF_ABLATE 0
-#endif
-
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -614,21 +610,7 @@ __global__ __launch_bounds__(kBlock * TPB, TPB == 1 ? 3 : 1) void k_jac_fused(Pa
             q.b1 = qd[6], q.b2 = qd[7], q.b3 = qd[8], q.b4 = qd[9], q.t[0] = qd[10], q.t[1] = qd[11], q.t[2] = qd[12];
             PointOut<M> o;
             double jex[6], jey[6];
-#if CCALIB_JF_ABLATE == 3   // timing experiment: no point arithmetic, the LDS writes stay
-            static_for<0, NC>([&](auto ic_) { o.jx[decltype(ic_)::value] = q.c + m.x, o.jy[decltype(ic_)::value] = q.s + m.y; });
-            for (int b = 0; b < 6; b++) jex[b] = q.c1 + X, jey[b] = q.b1 + Y;
-            o.ex = m.x, o.ey = m.y;
-#else
             point_jacobian<M>(q, cp, (double)X, (double)Y, (double)Z, (double)m.x, (double)m.y, o, jex, jey);
-#endif
-#if CCALIB_JF_ABLATE == 4   // timing experiment: the point arithmetic stays, one LDS write instead of fourteen
-            {
-                double sx = o.ex, sy = o.ey;
-                static_for<0, NC>([&](auto ic_) { sx += o.jx[decltype(ic_)::value], sy += o.jy[decltype(ic_)::value]; });
-                for (int b = 0; b < 6; b++) sx += jex[b], sy += jey[b];
-                lds2[dst + ((slot(CRES) * RS) >> 1)] = make_double2(sx, sy);
-            }
-#else
             static_for<0, NC>([&](auto ic_) {
                 constexpr int i = decltype(ic_)::value;
                 if constexpr (!(CONSTC && (i == ICX || i == ICY)))
@@ -637,7 +619,6 @@ __global__ __launch_bounds__(kBlock * TPB, TPB == 1 ? 3 : 1) void k_jac_fused(Pa
 #pragma unroll
             for (int b = 0; b < 6; b++) lds2[dst + ((slot(CPOSE + b) * RS) >> 1)] = make_double2(jex[b], jey[b]);
             lds2[dst + ((slot(CRES) * RS) >> 1)] = make_double2(o.ex, o.ey);
-#endif
         }
         if (n < dirty) {  // rows past the chunk's last point must read as zero (wave-uniform branch)
             if (lane >= n && lane < dirty) {
@@ -659,19 +640,11 @@ __global__ __launch_bounds__(kBlock * TPB, TPB == 1 ? 3 : 1) void k_jac_fused(Pa
     };
     auto matrix_phase = [&](int n, Acc& acc, bool from_zero) {
         __builtin_amdgcn_wave_barrier();
-#if CCALIB_JF_ABLATE == 2   // timing experiment: no matrix phase at all
-        if (from_zero) acc = Acc{0., 0., 0., 0., 0.};
-        return;
-#endif
         // The point phase is one long chain of dependent FP64 instructions, the matrix phase independent work
         // that fills any gap: the wavefront issues at low priority here and at high priority outside.
         __builtin_amdgcn_s_setprio(0);
         const int ngroups = (2 * n + 7) >> 3;  // >= 1
         auto mfma5 = [&](const double2& u, const double2& u1, double ar, double br) {
-#if CCALIB_JF_ABLATE == 1   // timing experiment: the operand reads stay, the matrix instructions go
-            asm volatile("" ::"v"(u.x), "v"(u.y), "v"(u1.x), "v"(u1.y), "v"(ar), "v"(br));
-            return;
-#endif
             acc.d0 = __builtin_amdgcn_mfma_f64_4x4x4f64(u.x, u.x, acc.d0, 0, 0, 0);
             acc.e0 = __builtin_amdgcn_mfma_f64_4x4x4f64(u.x, u1.x, acc.e0, 0, 0, 0);
             acc.f = __builtin_amdgcn_mfma_f64_4x4x4f64(ar, br, acc.f, 0, 0, 0);

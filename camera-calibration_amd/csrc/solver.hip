@@ -33,8 +33,8 @@ using namespace ccalib;
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
         if (e_ != hipSuccess)                                                                      \
-            return set_error(CCALIB_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
-                             __FILE__, __LINE__);                                                  \
+            return set_error(CCALIB_ERR_HIP, "%s failed: %s (%s:%d)%s", #expr, hipGetErrorString(e_), \
+                             __FILE__, __LINE__, hip_runtime_note());                             \
     } while (0)
 #define NCCL_TRY(expr)                                                                              \
     do {                                                                                            \
@@ -1419,10 +1419,11 @@ int ccalib_solver_init_relative_pose(ccalib_solver* s, double* lr) {
         }
         return CCALIB_OK;
     }
-    // Sharded run: the median is taken over the views of ALL ranks, exactly.  Doubles are mapped to 64-bit keys
-    // in the same order; for every component the key of the wanted order statistic is found by bisection on the
-    // key, each round asking all ranks how many of their values lie at or below the probe (one all-reduce of twelve
-    // counts per round, 64 rounds).  Every rank ends with the same bits a single solver over all views computes.
+    // Sharded run: the median is taken over the views of ALL ranks, exactly.  Doubles are mapped to 64-bit keys in the
+    // same order; for every component the key of the wanted order statistic is found eight bits at a time: each round
+    // asks all ranks how many of their values lie at or below each of the 256 candidates that extend the bits found
+    // so far (one all-reduce of 12 x 256 counts per round, eight rounds).  Every rank ends with the same bits a single
+    // solver over all views computes.
     auto to_key = [](double v) {
         unsigned long long b;
         std::memcpy(&b, &v, 8);
@@ -1444,27 +1445,29 @@ int ccalib_solver_init_relative_pose(ccalib_solver* s, double* lr) {
     if (rc) return rc;
     const long long N = std::llround(cnt);
     // searches 0..5: order statistic N/2 of each component; 6..11: N/2 - 1 (used when N is even)
-    unsigned long long lo[12], hi[12];
+    unsigned long long prefix[12];
     long long want[12];
-    for (int j = 0; j < 12; j++) lo[j] = 0, hi[j] = ~0ull, want[j] = j < 6 ? N / 2 : std::max(0ll, N / 2 - 1);
-    for (int round = 0; round < 64; round++) {
-        double c[12];
-        unsigned long long mid[12];
+    for (int j = 0; j < 12; j++) prefix[j] = 0, want[j] = j < 6 ? N / 2 : std::max(0ll, N / 2 - 1);
+    static_assert(12 * 256 <= ccalib_solver::kRedCap, "the counts of one round go through the reduction buffer");
+    std::vector<double> c(12 * 256);
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        const unsigned long long low = shift ? (1ull << shift) - 1 : 0ull;
         for (int j = 0; j < 12; j++) {
-            mid[j] = lo[j] + (hi[j] - lo[j]) / 2;
             const auto& k = keys[j % 6];
-            c[j] = (double)(std::upper_bound(k.begin(), k.end(), mid[j]) - k.begin());
+            for (int b = 0; b < 256; b++) {  // values at or below the largest key that starts with prefix | b
+                const unsigned long long top = prefix[j] | ((unsigned long long)b << shift) | low;
+                c[j * 256 + b] = (double)(std::upper_bound(k.begin(), k.end(), top) - k.begin());
+            }
         }
-        if ((rc = allreduce_host(s, c, 12))) return rc;
+        if ((rc = allreduce_host(s, c.data(), 12 * 256))) return rc;
         for (int j = 0; j < 12; j++) {
-            if (std::llround(c[j]) >= want[j] + 1)
-                hi[j] = mid[j];
-            else
-                lo[j] = mid[j] + 1;
+            int b = 0;
+            while (b < 255 && std::llround(c[j * 256 + b]) < want[j] + 1) b++;
+            prefix[j] |= (unsigned long long)b << shift;
         }
     }
     for (int a = 0; a < 6; a++) {
-        const double vhi = from_key(lo[a]), vlo = from_key(lo[6 + a]);
+        const double vhi = from_key(prefix[a]), vlo = from_key(prefix[6 + a]);
         lr[a] = N % 2 ? vhi : (vlo + vhi) * 0.5;
     }
     return CCALIB_OK;
@@ -1495,9 +1498,35 @@ int ccalib_solver_use_callback(ccalib_solver* s, ccalib_allreduce_fn fn, void* u
     return CCALIB_OK;
 }
 
+// The ranks of a sharded run enqueue their collectives independently, each from its own copy of the host state
+// machine: they pair up only if every rank takes the same decisions about what to run ahead, with the same column
+// set and the same criteria.  One small all-reduce before the loop compares the settings that decide this (sum of
+// 1, w, w^2 over ranks: all w equal iff n * sum w^2 == (sum w)^2, by Cauchy-Schwarz) and refuses a mismatch instead of hanging later.
+static int check_rank_agreement(ccalib_solver* s, int term_type, int max_iter, int solve_method) {
+    if (!s->comm && !s->cb) return CCALIB_OK;
+    // two words below 2^14: their squares, summed over up to a thousand ranks and multiplied by the rank count, stay
+    // exact in a double
+    const double w1 = (s->retry_enabled ? 1 : 0) + (s->speculate ? 2 : 0) + (s->chain_enabled ? 4 : 0) + (s->use_fused ? 8 : 0) +
+                      16. * (s->split_publish + 1) + 64. * (s->ncams - 1) + 128. * s->kcols() + 4096. * (s->fix_intrinsic ? 1 : 0) +
+                      8192. * (s->same_focal ? 1 : 0);
+    const double w2 = (term_type & 3) + 4. * (solve_method & 1) + 8. * std::min(std::max(max_iter, 0), 1000);
+    double buf[5] = {1., w1, w1 * w1, w2, w2 * w2};
+    int rc = allreduce_host(s, buf, 5);
+    if (rc) return rc;
+    if (buf[0] * buf[2] != buf[1] * buf[1] || buf[0] * buf[4] != buf[3] * buf[3])
+        return set_error(CCALIB_ERR_STATE, "the ranks of this sharded run do not agree on their settings (environment switches such as "
+                                           "CCALIB_NO_AHEAD / CCALIB_NO_RETRY_AHEAD / CCALIB_CHAIN, the free-parameter set, the solver or the "
+                                           "criteria): every rank must be configured alike, or their all-reduces do not pair up");
+    return CCALIB_OK;
+}
+
 int ccalib_solver_run(ccalib_solver* s, int term_type, int max_iter, double eps, int solve_method, ccalib_stats* stats) {
     if (!s || !s->started) return set_error(CCALIB_ERR_STATE, "ccalib_solver_run before ccalib_solver_set_start");
     HIP_TRY(hipSetDevice(s->device));
+    {
+        int rc0 = check_rank_agreement(s, term_type, max_iter, solve_method);
+        if (rc0) return rc0;
+    }
     ccalib_backend be;
     be.ns = s->ns();
     be.jac = be_jac, be.reduce = be_reduce, be.step_err = be_step_err, be.commit = be_commit, be.fixup = be_fixup;
@@ -1842,11 +1871,13 @@ __global__ __launch_bounds__(kNaBlock) void k_na_prepare(const int* __restrict__
 // order; NaN everywhere when the table was invalid.
 __global__ __launch_bounds__(kNaBlock) void k_na_finish(const int* __restrict__ off, const int* __restrict__ bad,
                                                         const double* __restrict__ verr, int nviews, double* per_view_rms,
-                                                        double* total_rms) {
+                                                        double* total_rms, float2* proj) {
     __shared__ double sm[kNaBlock];
     const int t = threadIdx.x;
     const bool invalid = *bad != 0;
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    // a caller that asked for projections only still learns that nothing was projected: the first pixel reads NaN
+    if (invalid && proj && t == 0) proj[0] = make_float2(__int_as_float(0x7fc00000), __int_as_float(0x7fc00000));
     double s = 0;
     for (int i = t; i < nviews; i += kNaBlock) {
         const double e = invalid ? nan : verr[i];
@@ -1882,6 +1913,20 @@ extern "C" int ccalib_reprojection_error_noalloc(int nviews, const int* d_npts, 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return set_error(CCALIB_ERR_NO_DEVICE, "no HIP device is usable (this library has no CPU path)");
+    {   // Two HIP runtimes in one process (the caller's framework loaded after this library): the caller's device
+        // pointers and stream then belong to the other copy and every launch below would fail with a bare "invalid
+        // argument".  Found here instead: a device pointer this runtime does not know, while two copies are mapped.
+        static thread_local int copies = -1;
+        if (copies < 0) copies = hip_runtime_copies(nullptr, 0);
+        if (copies > 1) {
+            hipPointerAttribute_t at;
+            if (hipPointerGetAttributes(&at, d_img_uv) != hipSuccess) {
+                (void)hipGetLastError();
+                return set_error(CCALIB_ERR_STATE, "reprojection_error_noalloc: d_img_uv is not a device pointer of this library's HIP runtime%s",
+                                 hip_runtime_note());
+            }
+        }
+    }
     unsigned char* base = nullptr;
     int rc = scratch_for_current_device(&base);
     if (rc) return rc;
@@ -1919,8 +1964,8 @@ extern "C" int ccalib_reprojection_error_noalloc(int nviews, const int* d_npts, 
     hipLaunchKernelGGL(k_na_prepare, dim3(1), dim3(kNaBlock), 0, st, d_npts, nviews, max_npts, capacity, d_rvecs, d_tvecs, off,
                        bad, pose);
     launch_reproj(a, cp, rational, grid, reinterpret_cast<float2*>(d_proj_uv), verr, st, bad);
-    if (d_per_view_rms || d_total_rms)
-        hipLaunchKernelGGL(k_na_finish, dim3(1), dim3(kNaBlock), 0, st, off, bad, verr, nviews, d_per_view_rms, d_total_rms);
+    hipLaunchKernelGGL(k_na_finish, dim3(1), dim3(kNaBlock), 0, st, off, bad, verr, nviews, d_per_view_rms, d_total_rms,
+                       reinterpret_cast<float2*>(d_proj_uv));
     HIP_TRY(hipGetLastError());
     return CCALIB_OK;
 }

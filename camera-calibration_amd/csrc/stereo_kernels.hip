@@ -595,9 +595,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
         for (int k = 0; k < 6; k++) invd[k] = 0.;
     }
-    chol6_fwd(L, invd, y);
+    // ... unless the view's blocks hold Inf or NaN (the usual reason a factorisation fails): 0 * NaN is NaN.  Then the
+    // forward-solved rows are cleared outright, as the four-lane kernel does.  The test is wave-uniform and false in
+    // any healthy run, so the selects below cost a scalar branch.
+    const bool any_out = __builtin_amdgcn_ballot_w64(!use && live) != 0;
+    auto clear_row = [&](double z[6]) {
+        if (any_out) {
 #pragma unroll
-    for (int r = 0; r < 6; r++) chol6_fwd(L, invd, ZL[r]);
+            for (int b = 0; b < 6; b++) z[b] = use ? z[b] : 0.;
+        }
+    };
+    chol6_fwd(L, invd, y);
+    clear_row(y);
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        chol6_fwd(L, invd, ZL[r]);
+        clear_row(ZL[r]);
+    }
     auto dot = [&](const double p[6], const double q[6]) {
         double d = 0;
 #pragma unroll
@@ -608,6 +622,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
         for (int b = 0; b < 6; b++) z[b] = blk0[blk_index(NB, 27 + 6 * i + b, vv)];
         chol6_fwd(L, invd, z);
+        clear_row(z);
     };
     {   // pass A
         double Z0[NC][6];
@@ -640,6 +655,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             for (int b = 0; b < 6; b++) w[b] = blk1[blk_index(NB, 27 + 6 * i + b, vv)];
             times_A(w, Z1[i]);
             chol6_fwd(L, invd, Z1[i]);
+            clear_row(Z1[i]);
         }
 #pragma unroll
         for (int p = 0; p < 6; p++)

@@ -150,9 +150,14 @@ int ccalib_reprojection_error(int nviews, const int* npts, const float* obj_xyz,
  *   stream             a hipStream_t (NULL = the default stream); the work is enqueued there and the call returns
  *                      without waiting, so the outputs are valid once that stream reaches this point
  * A point count outside [4, max_npts] or a total beyond `capacity` is found on the device: d_per_view_rms and
- * d_total_rms then receive NaN, d_proj_uv is left untouched and nothing is read past the stated sizes.
+ * d_total_rms then receive NaN, the first pixel of d_proj_uv receives (NaN, NaN) and the rest of d_proj_uv is left
+ * untouched; nothing is read past the stated sizes.
  * All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two threads) race;
  * calls enqueued on one stream are ordered and safe.
+ * Under HIP graph capture: make one ordinary call on the device first (the first call per device asks the runtime for
+ * the array's address, which may load the code object and is not a capturable operation); after that a call issues
+ * only kernel launches on `stream` and can be captured.  K, dist, nviews, max_npts and capacity are kernel arguments
+ * by value: they are baked into the captured graph, the arrays behind the device pointers are read at replay.
  */
 int ccalib_reprojection_error_noalloc(int nviews, const int* d_npts, int max_npts, int capacity,
                                       const float* d_obj_xyz, const float* d_img_uv, const double* K,

@@ -81,3 +81,42 @@ def test_config5_one_gpu_share_125k_pairs_properties(pkg, synth):
         assert np.allclose(oa["intr"][c, 4:9], cam.dist(5), atol=5e-3)
     assert np.abs(oa["rt"][:, :3] - rvec).max() < 6e-2      # a single noisy view determines its pose this well
     assert np.median(np.abs(oa["rt"][:, :3] - rvec)) < 1e-3
+
+
+def test_a_view_with_unusable_blocks_counts_for_nothing_in_both_sum_kernels(pkg, synth, monkeypatch):
+    """One pair out of 33 000 starts from a pose that is not a number: its blocks hold NaN, its 6 x 6 factorisation
+    fails, and it must drop out of the Schur sums -- 0 * NaN must not reach them -- in the one-lane-per-view kernel
+    (which large problems run) exactly as in the four-lanes-per-view kernel."""
+    obj = synth.chessboard(9, 6, 25.0)
+    N = 33_000
+    st = synth.make_stereo(obj, N, 0xC0FFEE + 3)
+    img2 = st.img2
+    intr = np.zeros((2, 18))
+    for c, cam in enumerate((st.cam1, st.cam2)):
+        intr[c, :4] = [cam.fx * 0.98, cam.fy * 0.985, cam.cx + 2.5, cam.cy - 2.0]
+        intr[c, 4:9] = cam.dist(5) * 0.8
+    mask = np.zeros((2, 18), dtype=np.uint8)
+    mask[:, :9] = 1
+    rt0 = synth.perturbed_poses(st.rvec, st.tvec, 3, rot_sigma=0.01, trans_sigma=3.0)
+    lr0 = np.r_[st.r_lr, st.t_lr] + np.array([1e-3, -1e-3, 5e-4, 0.5, -0.2, 0.3])
+    rt0[12_345, 4] = np.nan
+    sums = {}
+    for quad in ("0", "1"):
+        monkeypatch.setenv("CCALIB_SUMS_QUAD", quad)
+        s = pkg.Solver(obj, st.img1, img2)
+        s.set_start(intr, mask, rt0, lr=lr0)
+        s.eval_jacobian()
+        sums[quad] = s.reduce(1e-3, 24)
+        s.close()
+    (S0, b0), (S1, b1) = sums["0"], sums["1"]
+    assert np.isfinite(S0).all() and np.isfinite(b0).all() and np.isfinite(S1).all() and np.isfinite(b1).all()
+    assert np.allclose(S0, S1, rtol=1e-9, atol=1e-10 * np.abs(S1).max()) and np.allclose(b0, b1, rtol=1e-9, atol=1e-10 * np.abs(b1).max())
+    # and they are the sums over the other 32 999 pairs: the same problem without that pair gives them to round-off
+    keep = np.arange(N) != 12_345
+    monkeypatch.setenv("CCALIB_SUMS_QUAD", "0")
+    s = pkg.Solver(obj, st.img1[keep], img2[keep])
+    s.set_start(intr, mask, rt0[keep], lr=lr0)
+    s.eval_jacobian()
+    S2, b2 = s.reduce(1e-3, 24)
+    s.close()
+    assert np.allclose(S0, S2, rtol=1e-9, atol=1e-10 * np.abs(S2).max()) and np.allclose(b0, b2, rtol=1e-9, atol=1e-10 * np.abs(b2).max())
