@@ -279,6 +279,19 @@ class Solver:
         capi.check(self._lib.ccalib_solver_counters(self._h, c))
         return dict(ahead=c[0], used=c[1], dropped=c[2])
 
+    def describe(self):
+        """How the Jacobian pass runs: dict(kernel ('vector' | 'fused16' | 'fused12'), cams_per_launch, grid, ncols, ncams)."""
+        o = (C.c_int * 8)()
+        capi.check(self._lib.ccalib_solver_describe(self._h, o))
+        return dict(kernel=("vector", "fused16", "fused12")[o[0]], cams_per_launch=o[1], grid=o[2], ncols=o[3], ncams=o[4],
+                    sums_quad=bool(o[5]))
+
+    def profile_jac(self, on):
+        """Switches in-loop timing of the Jacobian launches on/off; returns (mean ms, launches) recorded so far."""
+        ms, n = C.c_double(), C.c_int()
+        capi.check(self._lib.ccalib_solver_profile_jac(self._h, C.c_int(1 if on else 0), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def eval_error(self):
         e = C.c_double()
         capi.check(self._lib.ccalib_solver_eval_error(self._h, C.byref(e)))

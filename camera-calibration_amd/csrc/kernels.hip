@@ -651,19 +651,21 @@ __global__ __launch_bounds__(kBlock * TPB, TPB == 1 ? 3 : 1) void k_jac_fused(Pa
             acc.d1 = __builtin_amdgcn_mfma_f64_4x4x4f64(u.y, u.y, acc.d1, 0, 0, 0);
             acc.e1 = __builtin_amdgcn_mfma_f64_4x4x4f64(u.y, u1.y, acc.e1, 0, 0, 0);
         };
-        int oN = srcN, oN1 = srcN1, oA = srcA, oB = srcB;
-        double2 pn = lds2r[oN], pn1 = lds2r[oN1];
-        double pa = ldsd[oA], pb = ldsd[oB];
+        // unrolled over the sixteen groups a chunk can have, so that every read is a base address plus an immediate
+        // offset: no address arithmetic on the vector ALU inside the phase, only scalar compares and branches
+        double2 pn = lds2r[srcN], pn1 = lds2r[srcN1];
+        double pa = ldsd[srcA], pb = ldsd[srcB];
         if (from_zero) acc = Acc{0., 0., 0., 0., 0.};
-        for (int g = 0; g < ngroups; g += 2) {
-            const double2 qn = lds2r[oN + 4], qn1 = lds2r[oN1 + 4];
-            const double qa = ldsd[oA + 8], qb = ldsd[oB + 8];
+#pragma unroll
+        for (int g = 0; g < 16; g += 2) {
+            if (g >= ngroups) break;
+            const double2 qn = lds2r[srcN + 4 * (g + 1)], qn1 = lds2r[srcN1 + 4 * (g + 1)];
+            const double qa = ldsd[srcA + 8 * (g + 1)], qb = ldsd[srcB + 8 * (g + 1)];
             __builtin_amdgcn_sched_barrier(0);
             mfma5(pn, pn1, pa, pb);
             if (g + 1 >= ngroups) break;
-            oN += 8, oN1 += 8, oA += 16, oB += 16;
-            pn = lds2r[oN], pn1 = lds2r[oN1];
-            pa = ldsd[oA], pb = ldsd[oB];
+            pn = lds2r[srcN + 4 * (g + 2)], pn1 = lds2r[srcN1 + 4 * (g + 2)];
+            pa = ldsd[srcA + 8 * (g + 2)], pb = ldsd[srcB + 8 * (g + 2)];
             __builtin_amdgcn_sched_barrier(0);
             mfma5(qn, qn1, qa, qb);
         }

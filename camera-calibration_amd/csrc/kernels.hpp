@@ -75,6 +75,29 @@ struct ModelOps {
     }
 };
 
+// The fused pass on a 12-column tile (fused12.hip): column sets of at most six intrinsics with cx and cy among them,
+// every camera of the solver in one launch (grid.y = camera).  All cameras share the view table, the object points and
+// the column set; what differs per camera travels in Fused12Cam.
+struct Fused12Cam {
+    CamParams cp;
+    const float2* img;   // the camera's image points
+    const double* pc;    // its pose records (nviews x kPoseConstStride)
+    double* blk;         // its per-view blocks
+    double* part;        // its shared-block partial sums: `grid` rows of NRED_U
+};
+struct Fused12Cams {
+    Fused12Cam c[2];
+};
+struct Fused12Geom {
+    int CH, RS;
+    unsigned lds_bytes;
+};
+Fused12Geom fused12_geom(int maxnp, bool shared_board, int board_np, int tiles);
+bool has_jac_fused12(unsigned mask, bool aspect, bool rational);
+// false: the column set is not built for this tile, or a view does not fit its LDS geometry
+bool launch_jac_fused12(unsigned mask, bool aspect, bool rational, const PassArgs& a, const Fused12Cams& cams, int ncams, int grid,
+                        hipStream_t st);
+
 // Smallest built-in column set that covers `need_mask` (bits over the 12 modelled intrinsics).
 const ModelOps* find_model(unsigned need_mask, bool aspect, bool need_rational);
 // sum of squared residuals from pose records (pc: nviews x kPoseConstStride), one wavefront per view

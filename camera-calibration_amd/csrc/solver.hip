@@ -59,6 +59,8 @@ struct ccalib_solver {
     int grid_view = 0;  // per-view kernels: every wavefront does one round
     int grid_red = 0;   // reducing kernels: fewer workgroups, several rounds each, one reduction at the end
     int grid_fused = 0; // fused Jacobian kernel: workgroups striding over tiles of kTileViews views
+    int grid_fused12 = 0;  // the same for the 12-column kernel, which takes every camera in one launch
+    bool use_tile12 = true;  // CCALIB_NO_TILE12=1: column sets that fit the 12-column tile use the 16-column kernel
     int grid_err = 0;   // residual kernel: one wavefront per view, striding
     bool use_fused = true;
     unsigned lds_bytes = 0;
@@ -167,7 +169,9 @@ struct ccalib_solver {
         Trial t;
     } retry;
     bool retry_enabled = true;            // CCALIB_NO_RETRY_AHEAD=1 turns it off
+    bool dual_backsub = false;            // CCALIB_DUAL_BACKSUB=1: the retry's back-substitution rides in the first trial's kernel
     double* d_pose_retry = nullptr;       // trial poses of such a retry (they must not touch the first trial's)
+    double* d_pc_retry = nullptr;         // ... and their records
     std::vector<double> com_U, com_gs;    // shared block and gradient of the committed Jacobian, as the driver holds them
     double com_shared[42];                // the committed point
     bool com_valid = false;
@@ -192,6 +196,11 @@ struct ccalib_solver {
     double drv_err = 0, committed_err = 0;  // residual sums as the driver holds them: latest trial / committed point
     long long n_ahead = 0, n_ahead_used = 0, n_ahead_dropped = 0;
     int slot_after() const { return slot ^ 1; }
+
+    // In-loop timing of the per-point Jacobian launches (ccalib_solver_profile_jac): an event before and after each
+    std::vector<hipEvent_t> prof_ev;
+    size_t prof_used = 0;
+    bool prof_on = false;
 
     // multi-GPU
     ncclComm_t comm = nullptr;
@@ -345,7 +354,8 @@ size_t part_capacity(const ccalib_solver* s) {
     size_t n = 0;
     int kc = s->kcols();
     for (int c = 0; c < s->ncams; c++)
-        n += (size_t)std::max(s->grid_fused * kTileViews, s->grid_red) * s->ops[c]->NRED_U + 64 + (size_t)std::max(s->grid_red, s->grid_err) + 64;
+        n += (size_t)std::max(std::max(s->grid_fused, s->grid_fused12) * kTileViews, s->grid_red) * s->ops[c]->NRED_U + 64 +
+             (size_t)std::max(s->grid_red, s->grid_err) + 64;
     const size_t srows = s->ncams == 2 ? s->sums_rows : s->nblk64;
     n += 2 * (srows * (kc * (kc + 1) / 2 + kc) + 64);  // Schur sums, for up to two dampings in one pass
     n += (size_t)s->nblk64 * 2 + 64;                   // step norms
@@ -452,6 +462,25 @@ JacLayout jac_layout(const ccalib_solver* s) {
     return L;
 }
 
+// In-loop timing: an event on the solver's stream, from a pool that grows as needed (only while profiling is on).
+void prof_mark(ccalib_solver* s) {
+    if (!s->prof_on) return;
+    if (s->prof_used == s->prof_ev.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        s->prof_ev.push_back(e);
+    }
+    (void)hipEventRecord(s->prof_ev[s->prof_used++], s->stream);
+}
+
+// Whether the Jacobian pass runs as one launch of the 12-column fused kernel over all cameras.
+bool tile12_possible(const ccalib_solver* s) {
+    if (!s->use_tile12 || !s->use_fused) return false;
+    for (int c = 0; c < s->ncams; c++)
+        if (s->ops[c] != s->ops[0] || !has_jac_fused12(s->ops[c]->mask, s->ops[c]->aspect, s->ops[c]->rational)) return false;
+    return fused12_geom(s->maxnp, s->shared_board, s->board_np, 1).lds_bytes <= 64 * 1024;
+}
+
 // Enqueues a whole Jacobian pass into block buffer `buf`, with the Schur sums for `lambda_hint`; the reduced sums
 // land in the reduction buffer from `ofs` on, laid out as jac_layout() says.  The pass evaluates camera 0 at the
 // poses `pose` (records in d_pc must match them).  By-value parameters (the solver's current intrinsics and
@@ -463,6 +492,26 @@ int enqueue_jac(ccalib_solver* s, int buf, double lambda_hint, int ofs, const do
     if (rc) return rc;
     const JacLayout L = jac_layout(s);
     for (int i = 0; i < 6; i++) s->lr_jac[buf].v[i] = s->lr[i];
+    if (tile12_possible(s) && !ctrl) {
+        // every camera's fused pass in one launch on the 12-column tile
+        const ModelOps* m = s->ops[0];
+        Fused12Cams cams;
+        const int rows = s->grid_fused12;
+        for (int c = 0; c < s->ncams; c++) {
+            PART_TAKE(part, s, (size_t)rows * m->NRED_U);
+            double* pc = c == 0 ? s->d_pc : s->d_pc3;
+            bool& fresh = c == 0 ? s->pc_fresh : s->pc3_fresh;
+            if (!fresh) launch_pose_const(c == 0 ? pose : s->d_pose3, s->nviews, pc, s->stream);
+            fresh = true;
+            cams.c[c] = Fused12Cam{cam_params(s->intr[c], s->aspect[c]), s->d_img[c], pc, s->d_blk[c][buf], part};
+            if ((rc = queue_colsum(s, part, rows, m->NRED_U, ofs + L.cam_ofs[c]))) return rc;
+        }
+        if (s->ncams == 1) cams.c[1] = cams.c[0];
+        prof_mark(s);
+        if (!launch_jac_fused12(m->mask, m->aspect, m->rational, pass_args(s, 0, pose), cams, s->ncams, rows, s->stream))
+            return set_error(CCALIB_ERR_STATE, "the 12-column fused pass refused a problem it was selected for");
+        prof_mark(s);
+    } else
     for (int c = 0; c < s->ncams; c++) {
         const ModelOps* m = s->ops[c];
         CamParams cp = cam_params(s->intr[c], s->aspect[c]);
@@ -474,7 +523,9 @@ int enqueue_jac(ccalib_solver* s, int buf, double lambda_hint, int ofs, const do
             bool& fresh = c == 0 ? s->pc_fresh : s->pc3_fresh;
             if (!fresh && !ctrl) launch_pose_const(a.pose, s->nviews, pc, s->stream);
             fresh = true;
+            prof_mark(s);
             m->jac_fused(a, cp, pc, s->grid_fused, s->d_blk[c][buf], part, s->stream, ctrl, c);
+            prof_mark(s);
             if ((rc = queue_colsum(s, part, rows, m->NRED_U, ofs + L.cam_ofs[c]))) return rc;
         } else {
             PART_TAKE(part, s, (size_t)s->grid_red * m->NRED_U);
@@ -595,7 +646,7 @@ double retry_lambda(const ccalib_solver* s, double lambda) {
 
 bool chain_possible(const ccalib_solver* s) {
     return s->chain_enabled && s->speculate && !s->cb && s->ncams == 1 && s->run_solve_method == 1 && s->d_ctrl &&
-           s->ops[0]->jac_fused && s->use_fused && s->h_maps.nf > 0;
+           s->ops[0]->jac_fused && s->use_fused && s->h_maps.nf > 0 && !tile12_possible(s);
 }
 
 // Arguments of the k_lm_step that ends a Jacobian pass evaluated at `shared` (by value; a run-ahead iteration
@@ -803,10 +854,22 @@ bool trial_runs_ahead(const ccalib_solver* s, double lambda, int nth) {
     return (nth == 1 || s->prev_trials == nth) && s->level_accepted[lambda_level(lambda)];
 }
 
+// A retry whose step is known before the trial ahead of it is launched (plan_retry_ahead).
+struct RetryPlan {
+    double lambda2 = 0;
+    int nf = 0;
+    double dsh[42], shared[42];
+};
+
 // Enqueues a trial step -- back-substitution into s->d_pose_cur, then either the Jacobian pass run ahead or the
 // residual pass -- and submits its reduction.  Does not wait.
+//   second        (stereo) the planned retry behind this trial: its back-substitution is taken along in this trial's
+//                 kernel -- one read of the blocks for both -- into d_pose_retry / d_pc_retry, its step norms into
+//                 the first 2 * nblk64 doubles of the other slot's arena, where the retry's own pass looks for them
+//   backsub_done  this trial's back-substitution was taken along that way: nothing to launch for it
 int launch_trial(ccalib_solver* s, double lambda, double lambda_next, const int* fidx, int nf, const double* dshared,
-                 const double* shared_new, int nth, ccalib_solver::Trial* t) {
+                 const double* shared_new, int nth, ccalib_solver::Trial* t, const RetryPlan* second = nullptr,
+                 bool backsub_done = false) {
     int rc;
     const int cur = s->cur, ns = s->ns();
     bool stereo_composed = false;
@@ -815,7 +878,11 @@ int launch_trial(ccalib_solver* s, double lambda, double lambda_next, const int*
     const bool ahead = trial_runs_ahead(s, lambda, nth);
     PART_TAKE(npart, s, (size_t)s->nblk64 * 2);
     const auto tl0 = std::chrono::steady_clock::now();
-    if (s->ncams == 1) {
+    if (backsub_done) {
+        const bool want_pc = s->ops[0]->jac_fused && s->use_fused;
+        s->pc_fresh = want_pc;
+        s->pc3_fresh = false;
+    } else if (s->ncams == 1) {
         DeltaC dc;
         for (int k = 0; k < I_NMODEL; k++) dc.v[k] = 0;
         for (int k = 0; k < s->ops[0]->NC; k++) dc.v[k] = dfull[s->ops[0]->col(k)];
@@ -834,10 +901,21 @@ int launch_trial(ccalib_solver* s, double lambda, double lambda_next, const int*
         const bool compose_here = !ahead;
         StereoLR lr_new;
         for (int i = 0; i < 6; i++) lr_new.v[i] = shared_new[i];
+        StereoSecondTrial st2;
+        if (second) {
+            std::vector<double> d2(ns, 0.);
+            for (int a = 0; a < second->nf; a++) d2[fidx[a]] = second->dsh[a];
+            for (int k = 0; k < kStereoMaxCols; k++)
+                st2.d.v[k] = k < kc && s->kcol_to_shared(k) < ns ? d2[s->kcol_to_shared(k)] : 0.;
+            st2.lambda = second->lambda2;
+            st2.pose = s->d_pose_retry;
+            st2.pc = want_pc ? s->d_pc_retry : nullptr;
+            st2.part = s->d_part[s->slot ^ 1];
+        }
         if (!launch_stereo_backsub(s->ops[0]->NC, s->d_blk[0][cur], s->d_blk[1][cur], s->d_cmp[cur], s->lr_jac[cur],
                                    s->npad, s->nviews, lambda, sd, s->d_pose_prev, s->d_pose_cur, npart,
                                    want_pc ? s->d_pc : nullptr, lr_new, compose_here ? s->d_pose3 : nullptr,
-                                   compose_here ? s->d_pc3 : nullptr, s->stream))
+                                   compose_here ? s->d_pc3 : nullptr, s->stream, second ? &st2 : nullptr))
             return set_error(CCALIB_ERR_UNSUPPORTED, "stereo column count %d is not built in", s->ops[0]->NC);
         s->pc_fresh = want_pc;
         s->pc3_fresh = compose_here;
@@ -884,29 +962,42 @@ int launch_trial(ccalib_solver* s, double lambda, double lambda_next, const int*
 // kernels put into the stream behind the first trial's, so that the GPU does not idle through a host turn-around
 // between the two.  The retry writes its poses to a buffer of its own; the driver's call is answered from it only
 // when damping, step and trial point are bit for bit the ones prepared here.
-int launch_retry_ahead(ccalib_solver* s, double lambda, const int* fidx, int nf) {
-    ccalib_solver::Retry& r = s->retry;
+// The plan: whether such a retry can be prepared now, and its step.
+bool plan_retry_ahead(ccalib_solver* s, double lambda, const int* fidx, int nf, RetryPlan* plan, int* rc_out) {
+    *rc_out = CCALIB_OK;
     const int lv = lambda_level(lambda), ns = s->ns();
-    if (!s->retry_enabled || !s->speculate || chain_possible(s) || !s->com_valid || s->cb || lv >= 32 || nf > 42) return CCALIB_OK;
+    if (!s->retry_enabled || !s->speculate || chain_possible(s) || !s->com_valid || s->cb || lv >= 32 || nf > 42) return false;
     const double lambda2 = std::exp((lv + 1 - 16) * std::log(10.));
-    if (!s->have_cached2 || s->cached_lambda2 != lambda2) return CCALIB_OK;
+    if (!s->have_cached2 || s->cached_lambda2 != lambda2) return false;
     std::vector<double> Ssum((size_t)nf * nf), bsum(nf);
-    int rc = map_schur_sums(s, s->cachedS2, fidx, nf, Ssum.data(), bsum.data());
-    if (rc) return rc;
+    if ((*rc_out = map_schur_sums(s, s->cachedS2, fidx, nf, Ssum.data(), bsum.data()))) return false;
     double prev[42];
     std::memcpy(prev, s->com_shared, sizeof(double) * ns);
     lm_trial_step(ns, nf, fidx, s->com_U.data(), s->com_gs.data(), Ssum.data(), bsum.data(), lambda2, s->run_solve_method, prev,
-                  r.shared, r.dsh);
-    be_fixup(s, r.shared, prev);
+                  plan->shared, plan->dsh);
+    be_fixup(s, plan->shared, prev);
+    plan->lambda2 = lambda2;
+    plan->nf = nf;
+    return true;
+}
+
+// Puts the planned retry into the stream behind the trial just launched.
+int launch_retry_ahead(ccalib_solver* s, double lambda, const int* fidx, int nf, const RetryPlan& plan, bool backsub_done) {
+    ccalib_solver::Retry& r = s->retry;
+    const int lv = lambda_level(lambda), ns = s->ns();
+    std::memcpy(r.shared, plan.shared, sizeof(double) * ns);
+    std::memcpy(r.dsh, plan.dsh, sizeof(double) * nf);
     // as be_step_err will see the damping history when the driver asks: this level rejected
     const bool was = s->level_accepted[lv];
     s->level_accepted[lv] = false;
     std::swap(s->d_pose_cur, s->d_pose_retry);
-    rc = launch_trial(s, lambda2, lambda, fidx, nf, r.dsh, r.shared, s->steps_since_jac + 1, &r.t);
+    std::swap(s->d_pc, s->d_pc_retry);
+    int rc = launch_trial(s, plan.lambda2, lambda, fidx, nf, r.dsh, r.shared, s->steps_since_jac + 1, &r.t, nullptr, backsub_done);
     std::swap(s->d_pose_cur, s->d_pose_retry);
+    std::swap(s->d_pc, s->d_pc_retry);
     s->level_accepted[lv] = was;
     if (rc) return rc;
-    r.lambda = lambda2, r.lambda_next = lambda, r.nf = nf, r.cur = s->cur;
+    r.lambda = plan.lambda2, r.lambda_next = lambda, r.nf = nf, r.cur = s->cur;
     r.inflight = true;
     s->n_ahead++;
     return CCALIB_OK;
@@ -964,7 +1055,8 @@ int be_step_err(void* user, double lambda, double lambda_next, const int* fidx, 
                            std::memcmp(dshared, r.dsh, sizeof(double) * nf) == 0 &&
                            std::memcmp(shared_new, r.shared, sizeof(double) * ns) == 0;
         if (match) {
-            std::swap(s->d_pose_cur, s->d_pose_retry);  // its poses are the trial poses now
+            std::swap(s->d_pose_cur, s->d_pose_retry);  // its poses (and their records) are the trial poses now
+            std::swap(s->d_pc, s->d_pc_retry);
             store_shared(s, shared_new);
             t = r.t;
             launched = true;
@@ -975,8 +1067,18 @@ int be_step_err(void* user, double lambda, double lambda_next, const int* fidx, 
         }
     }
     if (!launched) {
-        if ((rc = launch_trial(s, lambda, lambda_next, fidx, nf, dshared, shared_new, s->steps_since_jac, &t))) return rc;
-        if (!t.ahead && (rc = launch_retry_ahead(s, lambda, fidx, nf))) return rc;
+        // a trial that gets a residual pass only is expected to be rejected: its retry is planned first, so that (stereo)
+        // one kernel can do the back-substitution of both
+        RetryPlan plan;
+        bool planned = false;
+        if (!trial_runs_ahead(s, lambda, s->steps_since_jac)) {
+            planned = plan_retry_ahead(s, lambda, fidx, nf, &plan, &rc);
+            if (rc) return rc;
+        }
+        const bool dual = planned && s->ncams == 2 && s->dual_backsub;
+        if ((rc = launch_trial(s, lambda, lambda_next, fidx, nf, dshared, shared_new, s->steps_since_jac, &t, dual ? &plan : nullptr)))
+            return rc;
+        if (!t.ahead && planned && (rc = launch_retry_ahead(s, lambda, fidx, nf, plan, dual))) return rc;
         if (s->retry.inflight) store_shared(s, shared_new);  // the solver's parameters are this trial's until the driver moves on
     }
     if ((rc = wait_reduction(s, t.p, t.n))) return rc;
@@ -1114,6 +1216,10 @@ int ccalib_solver_create(ccalib_solver** out, int device, int ncams, int nviews,
     if (const char* e = std::getenv("CCALIB_GRID_FUSED"))
         s->grid_fused = std::max(1, std::min((nviews + kTileViews - 1) / kTileViews, std::atoi(e)));
     s->grid_fused = (s->grid_fused + 2) / 3 * 3;  // a workgroup may own three tiles; tiles past the last view do nothing
+    // all cameras in one launch: the same number of tile slots in flight, shared between them
+    s->grid_fused12 = std::min((nviews + kTileViews - 1) / kTileViews, 768 / ncams);
+    s->grid_fused12 = (s->grid_fused12 + 2) / 3 * 3;
+    if (const char* e = std::getenv("CCALIB_NO_TILE12")) s->use_tile12 = std::atoi(e) == 0;
     if (const char* e = std::getenv("CCALIB_NO_FUSED")) s->use_fused = std::atoi(e) == 0;
     s->grid_err = std::min((nviews + 3) / 4, 2048);  // eight wavefronts per SIMD
     if (const char* e = std::getenv("CCALIB_NO_AHEAD")) s->speculate = std::atoi(e) == 0;
@@ -1137,6 +1243,7 @@ int ccalib_solver_create(ccalib_solver** out, int device, int ncams, int nviews,
     HIP_TRY(hipMalloc(&s->d_pose_retry, sizeof(double) * 6 * nviews));
     HIP_TRY(hipMemset(s->d_pose_prev, 0, sizeof(double) * 6 * nviews));
     HIP_TRY(hipMalloc(&s->d_pc, sizeof(double) * kPoseConstStride * nviews));
+    HIP_TRY(hipMalloc(&s->d_pc_retry, sizeof(double) * kPoseConstStride * nviews));
     if (ncams == 2) {
         HIP_TRY(hipMalloc(&s->d_pose3, sizeof(double) * 6 * nviews));
         HIP_TRY(hipMalloc(&s->d_pc3, sizeof(double) * kPoseConstStride * nviews));
@@ -1155,6 +1262,7 @@ int ccalib_solver_create(ccalib_solver** out, int device, int ncams, int nviews,
     std::memset(&s->h_maps, 0, sizeof(LmMaps));
     if (const char* e = std::getenv("CCALIB_CHAIN")) s->chain_enabled = std::atoi(e) != 0;
     if (const char* e = std::getenv("CCALIB_NO_RETRY_AHEAD")) s->retry_enabled = std::atoi(e) == 0;
+    if (const char* e = std::getenv("CCALIB_DUAL_BACKSUB")) s->dual_backsub = std::atoi(e) != 0;
     if (const char* e = std::getenv("CCALIB_SPLIT_PUBLISH")) s->split_publish = std::atoi(e) != 0;
     HIP_TRY(hipMalloc(&s->d_counter, sizeof(unsigned)));
     HIP_TRY(hipMemset(s->d_counter, 0, sizeof(unsigned)));
@@ -1173,6 +1281,7 @@ void ccalib_solver_destroy(ccalib_solver* s) {
     (void)hipFree(s->d_pose_prev), (void)hipFree(s->d_pose_cur), (void)hipFree(s->d_pose3);
     (void)hipFree(s->d_sums_tab);
     (void)hipFree(s->d_pose_retry);
+    (void)hipFree(s->d_pc_retry);
     (void)hipFree(s->d_view_tab);
     for (int b = 0; b < 2; b++) (void)hipFree(s->d_cmp[b]), (void)hipFree(s->d_blk[0][b]), (void)hipFree(s->d_blk[1][b]);
     (void)hipFree(s->d_pc), (void)hipFree(s->d_pc3), (void)hipFree(s->d_ctrl), (void)hipFree(s->d_maps);
@@ -1183,6 +1292,7 @@ void ccalib_solver_destroy(ccalib_solver* s) {
     }
     (void)hipFree(s->d_status), (void)hipFree(s->d_pose_init1), (void)hipFree(s->d_parked_view), (void)hipFree(s->d_parked_state);
     (void)hipFree(s->d_counter);
+    for (hipEvent_t e : s->prof_ev) (void)hipEventDestroy(e);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -1590,6 +1700,39 @@ int ccalib_solver_counters(ccalib_solver* s, long long out[3]) {
     return CCALIB_OK;
 }
 
+int ccalib_solver_describe(ccalib_solver* s, int out[8]) {
+    if (!s || !s->started || !out) return set_error(CCALIB_ERR_STATE, "describe: a started solver and an output needed");
+    for (int i = 0; i < 8; i++) out[i] = 0;
+    const bool fused = s->ops[0]->jac_fused && s->use_fused;
+    const bool t12 = tile12_possible(s);
+    out[0] = t12 ? 2 : fused ? 1 : 0;
+    out[1] = t12 ? s->ncams : 1;
+    out[2] = t12 ? s->grid_fused12 : fused ? s->grid_fused : s->grid_view;
+    out[3] = s->ops[0]->NC;
+    out[4] = s->ncams;
+    out[5] = s->sums_quad ? 1 : 0;
+    return CCALIB_OK;
+}
+
+int ccalib_solver_profile_jac(ccalib_solver* s, int on, double* mean_ms, int* launches) {
+    if (!s) return set_error(CCALIB_ERR_ARG, "profile_jac: null solver");
+    HIP_TRY(hipSetDevice(s->device));
+    if (mean_ms || launches) {  // read what was recorded since profiling was switched on
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        double tot = 0;
+        int n = 0;
+        for (size_t i = 0; i + 1 < s->prof_used; i += 2) {
+            float t = 0;
+            if (hipEventElapsedTime(&t, s->prof_ev[i], s->prof_ev[i + 1]) == hipSuccess) tot += t, n++;
+        }
+        if (mean_ms) *mean_ms = n ? tot / n : 0.;
+        if (launches) *launches = n;
+    }
+    s->prof_on = on != 0;
+    s->prof_used = 0;
+    return CCALIB_OK;
+}
+
 int ccalib_solver_num_shared(ccalib_solver* s, int* ns) {
     if (!s || !ns) return set_error(CCALIB_ERR_ARG, "num_shared: bad arguments");
     *ns = s->ns();
@@ -1694,12 +1837,18 @@ int ccalib_solver_time_kernels(ccalib_solver* s, int reps, double ms[3]) {
     HIP_TRY(hipEventCreate(&e1));
     const ModelOps* m = s->ops[0];
     const bool fused = m->jac_fused && s->use_fused;
+    const bool t12 = tile12_possible(s);
     s->part_used = 0;
-    PART_TAKE(tpart, s, (size_t)std::max(std::max(s->grid_red, s->grid_err), s->grid_fused * kTileViews) * m->NRED_U);
+    PART_TAKE(tpart, s, t12 ? (size_t)2 * s->grid_fused12 * m->NRED_U + s->grid_err
+                            : (size_t)std::max(std::max(s->grid_red, s->grid_err), s->grid_fused * kTileViews) * m->NRED_U);
     s->part_used = 0;
     CamParams cp = cam_params(s->intr[0], s->aspect[0]);
     PassArgs a = pass_args(s, 0, s->d_pose_cur);
     if (fused) launch_pose_const(a.pose, s->nviews, s->d_pc, s->stream), s->pc_fresh = true;
+    if (fused && t12 && s->ncams == 2) {  // camera 1's pose records for the merged launch
+        int rc0 = stereo_compose(s, false, s->cur, s->d_pose_cur);
+        if (rc0) return rc0;
+    }
     for (int which = 0; which < 3; which++) {
         if (which == 0 && fused) {  // the fused kernel does the shared block as well
             ms[0] = 0.;
@@ -1708,7 +1857,15 @@ int ccalib_solver_time_kernels(ccalib_solver* s, int reps, double ms[3]) {
         auto launch = [&]() {
             if (which == 0)
                 m->jac_shared(a, cp, s->grid_red, tpart, s->stream);
-            else if (which == 1 && fused)
+            else if (which == 1 && fused && t12) {
+                Fused12Cams cams;
+                for (int c = 0; c < 2; c++) {
+                    const int cc = c < s->ncams ? c : 0;
+                    cams.c[c] = Fused12Cam{cam_params(s->intr[cc], s->aspect[cc]), s->d_img[cc], cc == 0 ? s->d_pc : s->d_pc3,
+                                           s->d_blk[cc][s->cur], tpart + (size_t)c * s->grid_fused12 * m->NRED_U};
+                }
+                launch_jac_fused12(m->mask, m->aspect, m->rational, a, cams, s->ncams, s->grid_fused12, s->stream);
+            } else if (which == 1 && fused)
                 m->jac_fused(a, cp, s->d_pc, s->grid_fused, s->d_blk[0][s->cur], tpart, s->stream, nullptr, 0);
             else if (which == 1)
                 m->jac_view(a, cp, s->grid_view, s->d_blk[0][s->cur], s->npad, s->stream);

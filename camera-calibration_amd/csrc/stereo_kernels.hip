@@ -679,11 +679,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     red.flush();
 }
 
-template <int NC0, int NC1>
+// DUAL: a second trial step from the same blocks in the same pass -- damping lambda2, step d2 -- whose poses go to
+// pose_cur2 (records to pc2, norms to part2).  The blocks are what the kernel waits for (1 224 bytes per pair at six
+// columns); the second factorisation and solve ride along for a few hundred instructions.
+template <int NC0, int NC1, bool DUAL>
 __global__ __launch_bounds__(64) void k_stereo_backsub(const double* blk0, const double* blk1, const double* cmp,
                                                        StereoLR lr, int npad, int nviews, double lambda, StereoDelta d,
                                                        const double* pose_prev, double* pose_cur, double* part, double* pc,
-                                                       StereoLR lr_new, double* pose3, double* pc3) {
+                                                       StereoLR lr_new, double* pose3, double* pc3, double lambda2,
+                                                       StereoDelta d2, double* pose_cur2, double* part2, double* pc2) {
     int v = blockIdx.x * 64 + threadIdx.x;
     bool live = v < nviews;
     int vv = live ? v : nviews - 1;
@@ -691,58 +695,82 @@ __global__ __launch_bounds__(64) void k_stereo_backsub(const double* blk0, const
     load_cmp(cmp, npad, vv, lr, c);
     ViewSys s;
     assemble_view<NC0, NC1>(blk0, blk1, npad, vv, c, s);
-    double rhs[6];
+    double rhs[6], rhs2[6];
 #pragma unroll
-    for (int k = 0; k < 6; k++) rhs[k] = s.ge[k];
+    for (int k = 0; k < 6; k++) rhs[k] = rhs2[k] = s.ge[k];
     {
         double WLR[6][6];
         Bt_times(c, s.M, WLR);
 #pragma unroll
         for (int a = 0; a < 6; a++)
 #pragma unroll
-            for (int b = 0; b < 6; b++) rhs[b] -= WLR[a][b] * d.v[a];
+            for (int b = 0; b < 6; b++) {
+                rhs[b] -= WLR[a][b] * d.v[a];
+                if constexpr (DUAL) rhs2[b] -= WLR[a][b] * d2.v[a];
+            }
     }
 #pragma unroll
     for (int i = 0; i < NC0; i++)
 #pragma unroll
-        for (int b = 0; b < 6; b++) rhs[b] -= blk0[blk_index((27 + 6 * NC0), 27 + 6 * i + b, vv)] * d.v[6 + i];
+        for (int b = 0; b < 6; b++) {
+            const double wv = blk0[blk_index((27 + 6 * NC0), 27 + 6 * i + b, vv)];
+            rhs[b] -= wv * d.v[6 + i];
+            if constexpr (DUAL) rhs2[b] -= wv * d2.v[6 + i];
+        }
     {
-        double acc[6] = {0, 0, 0, 0, 0, 0}, wa[6];  // (sum_i d_i W3_i) A
+        double acc[6] = {0, 0, 0, 0, 0, 0}, acc2[6] = {0, 0, 0, 0, 0, 0}, wa[6];  // (sum_i d_i W3_i) A
 #pragma unroll
         for (int i = 0; i < NC1; i++)
 #pragma unroll
-            for (int b = 0; b < 6; b++) acc[b] += blk1[blk_index((27 + 6 * NC1), 27 + 6 * i + b, vv)] * d.v[6 + NC0 + i];
+            for (int b = 0; b < 6; b++) {
+                const double wv = blk1[blk_index((27 + 6 * NC1), 27 + 6 * i + b, vv)];
+                acc[b] += wv * d.v[6 + NC0 + i];
+                if constexpr (DUAL) acc2[b] += wv * d2.v[6 + NC0 + i];
+            }
         row_times_A(c, acc, wa);
 #pragma unroll
         for (int b = 0; b < 6; b++) rhs[b] -= wa[b];
-    }
-    double L[21], invd[6];
-    bool ok = chol6(s.Vu, lambda, L, invd);
-    chol6_fwd(L, invd, rhs);
-    chol6_bwd(L, invd, rhs);
-    double dn = 0, pn = 0, pnew[6];
+        if constexpr (DUAL) {
+            row_times_A(c, acc2, wa);
 #pragma unroll
-    for (int k = 0; k < 6; k++) {
-        double pv = pose_prev[6 * (size_t)vv + k];
-        double dd = ok ? rhs[k] : 0.;
-        pnew[k] = pv - dd;
-        dn += dd * dd;
-        pn += pv * pv;
+            for (int b = 0; b < 6; b++) rhs2[b] -= wa[b];
+        }
     }
     __shared__ double sm[64 * 17];
     const int v0 = blockIdx.x * 64, nlive = min(64, nviews - v0);
-    wave_store_rows<6>(pnew, sm, pose_cur + 6 * (size_t)v0, nlive);
-    if (pc) {
-        double rec[16];
-        store_pose_const(pnew, rec);
-        wave_store_rows<16>(rec, sm, pc + 16 * (size_t)v0, nlive);
-    }
-    dn = wave_sum(live ? dn : 0.);
-    pn = wave_sum(live ? pn : 0.);
-    if (threadIdx.x == 0) {
-        part[2 * blockIdx.x] = dn;
-        part[2 * blockIdx.x + 1] = pn;
-    }
+    double prev[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) prev[k] = pose_prev[6 * (size_t)vv + k];
+    double pnew[6];
+    // one trial step: factorise V' for `lam`, solve, store the trial pose (and its record) and the step norms
+    auto trial = [&](double lam, double (&r)[6], double* pose_out, double* pc_out, double* part_out) {
+        double L[21], invd[6];
+        bool ok = chol6(s.Vu, lam, L, invd);
+        chol6_fwd(L, invd, r);
+        chol6_bwd(L, invd, r);
+        double dn = 0, pn = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            double dd = ok ? r[k] : 0.;  // a singular view block gets no update
+            pnew[k] = prev[k] - dd;
+            dn += dd * dd;
+            pn += prev[k] * prev[k];
+        }
+        wave_store_rows<6>(pnew, sm, pose_out + 6 * (size_t)v0, nlive);
+        if (pc_out) {
+            double rec[16];
+            store_pose_const(pnew, rec);
+            wave_store_rows<16>(rec, sm, pc_out + 16 * (size_t)v0, nlive);
+        }
+        dn = wave_sum(live ? dn : 0.);
+        pn = wave_sum(live ? pn : 0.);
+        if (threadIdx.x == 0) {
+            part_out[2 * blockIdx.x] = dn;
+            part_out[2 * blockIdx.x + 1] = pn;
+        }
+    };
+    if constexpr (DUAL) trial(lambda2, rhs2, pose_cur2, pc2, part2);
+    trial(lambda, rhs, pose_cur, pc, part);   // last: pnew is this trial's pose below
     if (pose3) {  // camera 1's trial pose (k_compose without the derivatives): (r3,t3) = lr_new o (r1,t1)
         double r1[3] = {pnew[0], pnew[1], pnew[2]}, r2[3] = {lr_new.v[0], lr_new.v[1], lr_new.v[2]};
         double R1[9], R2n[9], R3[9], p3[6];
@@ -812,9 +840,13 @@ template <int NC>
 static void backsub_t(dim3 grid, hipStream_t st, const double* blk0, const double* blk1, const double* cmp,
                       const StereoLR& lr, int npad, int nviews, double lambda, const StereoDelta& d,
                       const double* pose_prev, double* pose_cur, double* part, double* pc, const StereoLR& lr_new, double* pose3,
-                      double* pc3) {
-    hipLaunchKernelGGL((k_stereo_backsub<NC, NC>), grid, dim3(64), 0, st, blk0, blk1, cmp, lr, npad, nviews, lambda, d,
-                       pose_prev, pose_cur, part, pc, lr_new, pose3, pc3);
+                      double* pc3, const StereoSecondTrial* t2) {
+    if (t2)
+        hipLaunchKernelGGL((k_stereo_backsub<NC, NC, true>), grid, dim3(64), 0, st, blk0, blk1, cmp, lr, npad, nviews, lambda, d,
+                           pose_prev, pose_cur, part, pc, lr_new, pose3, pc3, t2->lambda, t2->d, t2->pose, t2->part, t2->pc);
+    else
+        hipLaunchKernelGGL((k_stereo_backsub<NC, NC, false>), grid, dim3(64), 0, st, blk0, blk1, cmp, lr, npad, nviews, lambda, d,
+                           pose_prev, pose_cur, part, pc, lr_new, pose3, pc3, 0., d, nullptr, nullptr, nullptr);
 }
 
 // column counts of the built-in column sets (kernels.hip)
@@ -964,10 +996,10 @@ bool launch_stereo_sums(int nc, const double* blk0, const double* blk1, const do
 bool launch_stereo_backsub(int nc, const double* blk0, const double* blk1, const double* cmp, const StereoLR& lr,
                            int npad, int nviews, double lambda, const StereoDelta& d, const double* pose_prev,
                            double* pose_cur, double* part, double* pc, const StereoLR& lr_new, double* pose3, double* pc3,
-                           hipStream_t st) {
+                           hipStream_t st, const StereoSecondTrial* second) {
     dim3 grid((nviews + 63) / 64);
     CCALIB_FOR_NC(nc, backsub_t, grid, st, blk0, blk1, cmp, lr, npad, nviews, lambda, d, pose_prev, pose_cur, part, pc, lr_new,
-                  pose3, pc3);
+                  pose3, pc3, second);
     return true;
 }
 

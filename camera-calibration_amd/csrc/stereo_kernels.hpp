@@ -63,11 +63,21 @@ bool launch_stereo_sums(int nc, const double* blk0, const double* blk1, const do
 int stereo_view_table(int nc, short* out);
 bool launch_stereo_view_sums(int nc, const double* blk0, const double* blk1, const double* cmp, const StereoLR& lr, int npad,
                              int nviews, double lambda, const short* dst, double* part, hipStream_t st);
+// A second trial step computed from the same read of the blocks (another damping, another step): its camera-0 poses,
+// their records (may be null) and its two step norms per 64 views go to buffers of its own.
+struct StereoSecondTrial {
+    double lambda;
+    StereoDelta d;
+    double* pose;
+    double* pc;
+    double* part;
+};
 bool launch_stereo_backsub(int nc, const double* blk0, const double* blk1, const double* cmp, const StereoLR& lr,
                            int npad, int nviews, double lambda, const StereoDelta& d, const double* pose_prev,
                            double* pose_cur, double* part, double* pc,  // pc: trial poses as records, or null
                            const StereoLR& lr_new, double* pose3, double* pc3,  // pose3 != null: camera 1's trial poses
-                           hipStream_t st);                                       // for the relative pose lr_new as well
+                           hipStream_t st,                                        // for the relative pose lr_new as well
+                           const StereoSecondTrial* second = nullptr);
 
 // The assembled stereo view systems of a Jacobian pass, for inspection (tests): V nviews x 36, ge nviews x 6,
 // W nviews x (6 + 2 nc) x 6 in kernel column order [om_LR T_LR | camera 0 | camera 1], all device pointers.

@@ -297,6 +297,21 @@ int ccalib_solver_get(ccalib_solver* s, double* intr, double* rt, double* lr, do
  *                  solver's stream: ms[0] shared-block Jacobian kernel, ms[1] per-view-block
  *                  Jacobian kernel, ms[2] residual kernel
  */
+/*
+ * How the solver runs its Jacobian pass (after set_start):  out[0] per-point kernel: 0 the two vector kernels, 1 the
+ * fused matrix-pipe kernel on a 16-column tile (one launch per camera), 2 the fused kernel on a 12-column tile (every
+ * camera in one launch);  out[1] cameras per launch;  out[2] workgroup slots of that launch;  out[3] intrinsic columns per
+ * camera;  out[4] cameras;  out[5] 1 when the stereo Schur sums take four lanes per view;  out[6..7] 0.
+ * ccalib_solver_time_kernels' ms[1] is the duration of ONE such launch (all out[1] cameras).
+ */
+int ccalib_solver_describe(ccalib_solver* s, int out[8]);
+/*
+ * Durations of the per-point Jacobian launches as they occur INSIDE ccalib_solver_run (between the kernels of a real
+ * iteration, not back to back): switches the recording of a HIP event before and after each such launch on or off;
+ * when mean_ms / launches are given, first waits for the stream and reports the mean duration and the number of
+ * launches recorded since the recording was switched on.  The events cost about a microsecond each: not for timed runs.
+ */
+int ccalib_solver_profile_jac(ccalib_solver* s, int on, double* mean_ms, int* launches);
 int ccalib_solver_num_shared(ccalib_solver* s, int* ns);
 int ccalib_solver_eval_error(ccalib_solver* s, double* err);
 int ccalib_solver_eval_jacobian(ccalib_solver* s, double* U, double* gs, double* err);
