@@ -41,7 +41,9 @@ MFMA_FLOPS = 2 * 4 * (4 * 4 * 4)     # v_mfma_f64_4x4x4_4b_f64: four 4x4x4 block
 BYTES_JAC_VIEW = (8 * 54 + 104 + 8 * (21 + 6 + 6 * 9)) / 54.0   # image points + pose record in, blocks out, per point
 PEAK_FP64_TFLOPS = 78.6    # MI355X dense FP64, matrix and vector alike (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
 PEAK_HBM_GBPS = 8000.0
-PROFILE_PMC = os.path.join(ROOT, "profiles", "r02_bench_pmc.json")   # rocprofv3 FETCH_SIZE / WRITE_SIZE passes
+PROFILE_PMC = os.path.join(ROOT, "profiles", "r03_bench_pmc.json")   # rocprofv3 FETCH_SIZE / WRITE_SIZE passes
+PROFILE_STEREO_PMC = os.path.join(ROOT, "profiles", "r03_stereo_pmc.json")
+REPEATS = 10               # further timed runs of the same K steps, for the spread of ms_per_step
 # stereoCalibrate with the reference's flag set: per camera fy cx cy k1 k2 k6 free, fx tied, rational model
 # (oracle/flopcount.py, stereo_reference_flags_6col_per_camera); a point pair is one point in each camera
 FLOPS_STEREO_PER_CAMERA_POINT = 473
@@ -51,7 +53,9 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=20,
+                    help="untimed LM iterations from the same start (as many as --steps by default, so that every kernel and "
+                         "code path of the timed run has already run once)")
     ap.add_argument("--views", type=int, default=100_000, help="views per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-views", type=int, default=4000, help="views in the bounded CPU sample")
@@ -137,21 +141,37 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_run():
+        """Exactly K LM iterations from the start point, bracketed by barrier + synchronize; max over ranks."""
+        solver.set_start(intr, mask, rt0)   # uploads the starting poses; untimed
+        barrier()
+        t0 = time.perf_counter()
+        st = solver.run(criteria=(3, args.steps, 0.0))   # eps = 0: exactly K iterations
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return st, dt
+
     # warm-up: W untimed LM iterations from the start point
     solver.set_start(intr, mask, rt0)
     if args.warmup > 0:
         solver.run(criteria=(3, args.warmup, 0.0))
-    solver.set_start(intr, mask, rt0)   # same start for the timed run (uploads poses; untimed)
-    barrier()
-    t0 = time.perf_counter()
-    st = solver.run(criteria=(3, args.steps, 0.0))   # eps = 0: exactly K iterations
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    exec0 = solver.executed_passes()
+    st, dt = timed_run()                     # THE timed region: value and ms_per_step come from this run alone
+    exec1 = solver.executed_passes()
     out = solver.get()
+    # the same K steps again, several times: how much a single run of a few milliseconds scatters
+    spread = [dt / args.steps * 1e3]
+    for _ in range(REPEATS):
+        spread.append(timed_run()[1] / args.steps * 1e3)
+    # and once more with a HIP event before and after every per-point Jacobian launch: the kernel's duration where
+    # it runs, between the other kernels of an iteration (the events cost time, so this is not the timed run)
+    solver.profile_jac(True)
+    timed_run()
+    inloop_ms, inloop_n = solver.profile_jac(False)
     points_local = V * obj.shape[0]
     points_total = points_local * world
     rms = float(np.sqrt(out["err"] / points_total))
@@ -163,7 +183,8 @@ def main():
         solver.set_start(out["intr"], mask, out["rt"])
         km = solver.time_kernels(reps=50)
         fused = km["jac_shared"] == 0.0      # the fused kernel covers the whole Jacobian pass
-        t_jac = km["jac_view"] * 1e-3
+        # priced on the in-loop launches when the pass is one kernel (the events bracket exactly that kernel)
+        t_jac = (inloop_ms if fused and inloop_n > 0 else km["jac_view"]) * 1e-3
         flops_alg = FLOPS_JAC_PASS if fused else FLOPS_JAC_VIEW
         achieved_tf = flops_alg * points_local / t_jac / 1e12
         P = int(obj.shape[0])
@@ -188,7 +209,11 @@ def main():
             "bound": "mfma", "kernel": "k_jac_fused" if fused else "k_jac_view", "achieved": round(achieved_tf, 3),
             "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved_tf / PEAK_FP64_TFLOPS, 4),
             "traffic": traffic, "traffic_source": traffic_source,
-            "launch_ms": round(km["jac_view"], 4),
+            "launch_ms": round(t_jac * 1e3, 4),
+            "launch_ms_source": ("HIP events around each of the %d launches inside a run of the timed region's %d steps "
+                                 "(a separate, identical run: the events cost time)" % (inloop_n, args.steps)) if fused and inloop_n > 0
+                                else "HIP events around 50 back-to-back launches",
+            "launch_ms_back_to_back": round(km["jac_view"], 4),
             "algorithmic_flops_per_point": flops_alg,
             "executed_flops_per_point": round(executed, 1) if executed else None,
             "executed_tflops": round(executed * points_local / t_jac / 1e12, 2) if executed else None,
@@ -220,16 +245,21 @@ def main():
         cpu = None
         whole = None
         stereo = None
+        other = None
         if not args.no_cpu and world == 1:   # the CPU leg and the whole-call leg are timed at N = 1 only
             cpu = cpu_baseline(ge, synth, obj, args.cpu_views, seed, pkg)
             cpu["opencv"] = opencv_check(pkg, synth)
             whole = whole_call(pkg, obj, ms)
             stereo = stereo_block(pkg, synth, local_rank, args.steps, args.warmup)
+            other = {"configs[1]": config1_block(pkg, synth, local_rank, args.steps, args.warmup),
+                     "configs[4] one-GPU share": config4_share_block(pkg, synth, local_rank, args.warmup)}
         result = {
             "metric": "residual+Jacobian point evaluations/s in the calibrateCamera LM loop (%s, 9x6 board)"
                       % (f"{args.views // 1000}k views/GPU" if args.scaling == "weak" else f"{args.views // 1000}k views in total"),
             "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "ms_per_step_min": min(spread), "ms_per_step_median": float(np.median(spread)),
+            "ms_per_step_max": max(spread), "ms_per_step_runs": len(spread),
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "configs[3]: monocular 9x6 chessboard, %d synthetic 640x480 views %s, "
                                    "flags=0 (9 free intrinsics), sharded by view"
@@ -237,9 +267,12 @@ def main():
                        "views_per_gpu": V,
                        "points_per_view": int(obj.shape[0]), "allreduce": mode},
             "lm_iters_per_sec": args.steps / dt,
-            "projected_points_per_sec": points_total * (st["jac_passes"] + st["err_passes"]) / dt,
+            # passes over all points that actually ran in the timed region (a residual pass the state machine asks for at
+            # a point whose Jacobian pass was run ahead is answered from that pass and does not run)
+            "projected_points_per_sec": points_total * ((exec1[0] - exec0[0]) + (exec1[1] - exec0[1])) / dt,
+            "executed_passes": {"jacobian": exec1[0] - exec0[0], "residual_only": exec1[1] - exec0[1]},
             "jac_passes": st["jac_passes"], "err_passes": st["err_passes"], "rms_px": rms,
-            "roofline": roofline, "cpu_baseline": cpu, "whole_call": whole, "stereo": stereo,
+            "roofline": roofline, "cpu_baseline": cpu, "whole_call": whole, "stereo": stereo, "other_configs": other,
         }
     solver.close()
     if dist is not None:
@@ -249,55 +282,171 @@ def main():
         print(json.dumps(result))
 
 
+def _stereo_start(pkg, synth, obj, st):
+    """Start of the stereo LM loop for the reference's flag set: averaged intrinsic guesses, perturbed poses."""
+    K = [pkg.init_camera_matrix_2d(obj, im[:2000], (640, 480)) for im in (st.img1, st.img2)]
+    intr = np.zeros((2, 18))
+    for c in range(2):      # CALIB_SAME_FOCAL_LENGTH averages the two guesses, as cvStereoCalibrateImpl does
+        intr[c, :4] = [(K[0][0, 0] + K[1][0, 0]) / 2, (K[0][1, 1] + K[1][1, 1]) / 2,
+                       (K[0][0, 2] + K[1][0, 2]) / 2, (K[0][1, 2] + K[1][1, 2]) / 2]
+    mask = np.zeros((2, 18), dtype=np.uint8)
+    mask[:, [1, 2, 3, 4, 5, 11]] = 1
+    aspect = [intr[0, 0] / intr[0, 1], intr[1, 0] / intr[1, 1]]
+    rt0 = synth.perturbed_poses(st.rvec, st.tvec, 3, rot_sigma=0.01, trans_sigma=3.0)
+    lr0 = np.r_[st.r_lr, st.t_lr] + np.array([1e-3, -1e-3, 5e-4, 0.5, -0.2, 0.3])
+    return dict(intr=intr, imask=mask, rt=rt0, aspect=aspect, same_focal=True, lr=lr0)
+
+
+def _timed_steps(s, start, steps, warmup, repeats=REPEATS):
+    """K LM iterations from `start`, timed; then `repeats` more runs for the spread and one with in-loop events."""
+    s.set_start(**start)
+    if warmup > 0:
+        s.run(criteria=(3, warmup, 0.0))
+    ms, stt = [], None
+    e0 = s.executed_passes()
+    for r in range(1 + repeats):
+        s.set_start(**start)
+        t0 = time.perf_counter()
+        got = s.run(criteria=(3, steps, 0.0))
+        ms.append((time.perf_counter() - t0) / steps * 1e3)
+        if r == 0:
+            stt, e1 = got, s.executed_passes()
+    s.profile_jac(True)
+    s.set_start(**start)
+    s.run(criteria=(3, steps, 0.0))
+    inloop_ms, inloop_n = s.profile_jac(False)
+    return dict(stats=stt, ms=ms, inloop_ms=inloop_ms, inloop_n=inloop_n, executed=(e1[0] - e0[0], e1[1] - e0[1]))
+
+
 def stereo_block(pkg, synth, dev, steps, warmup):
     """The stereoCalibrate LM loop (binocular_chessboard.cpp:152-162: its flag set, 9x6 board) on one GPU with the
     pairs resident in HBM: BASELINE configs[2] (10 000 pairs) and, because that size is bound by launch and host
     latencies rather than by the kernels, the same problem at 100 000 pairs.  A step is one LM iteration (both
-    cameras' Jacobian passes, the per-view rewrite and elimination, the 18x18 reduced solve, back-substitution,
+    cameras' Jacobian pass, the per-view rewrite and elimination, the 18x18 reduced solve, back-substitution,
     and the residual passes of rejected trial steps)."""
     obj = synth.chessboard(9, 6, 25.0)
     P = int(obj.shape[0])
     out = {}
+    try:
+        pmc = json.load(open(PROFILE_STEREO_PMC))
+    except (OSError, ValueError):
+        pmc = {}
     for label, pairs in (("configs[2]: 10k pairs", 10_000), ("100k pairs", 100_000)):
         st = synth.make_stereo(obj, pairs, 0xC0FFEE + 3)
-        K = [pkg.init_camera_matrix_2d(obj, im[:2000], (640, 480)) for im in (st.img1, st.img2)]
-        intr = np.zeros((2, 18))
-        for c in range(2):      # CALIB_SAME_FOCAL_LENGTH averages the two guesses, as cvStereoCalibrateImpl does
-            intr[c, :4] = [(K[0][0, 0] + K[1][0, 0]) / 2, (K[0][1, 1] + K[1][1, 1]) / 2,
-                           (K[0][0, 2] + K[1][0, 2]) / 2, (K[0][1, 2] + K[1][1, 2]) / 2]
-        mask = np.zeros((2, 18), dtype=np.uint8)
-        mask[:, [1, 2, 3, 4, 5, 11]] = 1
-        aspect = [intr[0, 0] / intr[0, 1], intr[1, 0] / intr[1, 1]]
-        rt0 = synth.perturbed_poses(st.rvec, st.tvec, 3, rot_sigma=0.01, trans_sigma=3.0)
-        lr0 = np.r_[st.r_lr, st.t_lr] + np.array([1e-3, -1e-3, 5e-4, 0.5, -0.2, 0.3])
         s = pkg.Solver(obj, st.img1, st.img2, device=dev)
-        s.set_start(intr, mask, rt0, aspect=aspect, same_focal=True, lr=lr0)
-        if warmup > 0:
-            s.run(criteria=(3, warmup, 0.0))
-        s.set_start(intr, mask, rt0, aspect=aspect, same_focal=True, lr=lr0)
-        t0 = time.perf_counter()
-        stt = s.run(criteria=(3, steps, 0.0))
-        dt = time.perf_counter() - t0
+        start = _stereo_start(pkg, synth, obj, st)
+        r = _timed_steps(s, start, steps, warmup)
         res = s.get()
-        km = s.time_kernels(reps=50)      # camera 0's fused Jacobian kernel alone, HIP events on the solver's stream
+        how = s.describe()
+        km = s.time_kernels(reps=50)      # the Jacobian launch alone, back to back, HIP events on the solver's stream
         s.close()
-        t_jac = km["jac_view"] * 1e-3
-        tf = FLOPS_STEREO_PER_CAMERA_POINT * pairs * P / t_jac / 1e12
+        stt, dt_ms = r["stats"], r["ms"][0]
+        cams = how["cams_per_launch"]
+        t_jac = (r["inloop_ms"] if r["inloop_n"] > 0 else km["jac_view"]) * 1e-3
+        tf = FLOPS_STEREO_PER_CAMERA_POINT * cams * pairs * P / t_jac / 1e12
+        traffic = traffic_source = None
+        for name, c in pmc.get(str(pairs), {}).items():   # counters of the committed passes, same kernel and size
+            if name.startswith("k_jac_fused12" if how["kernel"] == "fused12" else "k_jac_fused<"):
+                traffic = int((2 * c["FETCH_SIZE"]["mean_per_launch"] + c["WRITE_SIZE"]["mean_per_launch"]) * 1024)
+                traffic_source = ("committed rocprofv3 --pmc passes (%s), same kernel and size; not measured in this run"
+                                  % os.path.relpath(PROFILE_STEREO_PMC, ROOT))
+        bytes_alg = cams * pairs * (8 * P + 104 + 8 * (27 + 6 * how["ncols"]))
         out[label] = {
-            "pairs": pairs, "points_per_view": P, "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4),
-            "lm_iters_per_sec": round(steps / dt, 1),
-            "point_pairs_per_sec": pairs * P * stt["jac_passes"] / dt,
+            "pairs": pairs, "points_per_view": P, "steps": steps, "ms_per_step": round(dt_ms, 4),
+            "ms_per_step_min": round(min(r["ms"]), 4), "ms_per_step_median": round(float(np.median(r["ms"])), 4),
+            "ms_per_step_max": round(max(r["ms"]), 4),
+            "lm_iters_per_sec": round(1e3 / dt_ms, 1),
+            "point_pairs_per_sec": pairs * P * stt["jac_passes"] / (dt_ms * steps * 1e-3),
             "jac_passes": stt["jac_passes"], "err_passes": stt["err_passes"],
+            "executed_passes": {"jacobian": r["executed"][0], "residual_only": r["executed"][1]},
             "rms_px": float(np.sqrt(res["err"] / (2.0 * pairs * P))),
-            "roofline": {"bound": "mfma", "kernel": "k_jac_fused (6 columns, one launch per camera)",
-                         "launch_ms": round(km["jac_view"], 4), "achieved": round(tf, 3), "peak": PEAK_FP64_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(tf / PEAK_FP64_TFLOPS, 4),
-                         "algorithmic_flops_per_camera_point": FLOPS_STEREO_PER_CAMERA_POINT, "traffic": None},
+            "roofline": {"bound": "mfma",
+                         "kernel": "k_jac_fused12 (12-column tile, both cameras in one launch)" if how["kernel"] == "fused12"
+                                   else "k_jac_fused (16-column tile, one launch per camera)",
+                         "launch_ms": round(t_jac * 1e3, 4),
+                         "launch_ms_source": "HIP events around each of the %d launches inside a run of %d steps" % (r["inloop_n"], steps)
+                                             if r["inloop_n"] > 0 else "HIP events around 50 back-to-back launches",
+                         "launch_ms_back_to_back": round(km["jac_view"], 4), "cameras_per_launch": cams,
+                         "achieved": round(tf, 3), "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP64_TFLOPS, 4),
+                         "algorithmic_flops_per_camera_point": FLOPS_STEREO_PER_CAMERA_POINT,
+                         "algorithmic_bytes_per_launch": int(bytes_alg), "traffic": traffic, "traffic_source": traffic_source},
         }
     out["note"] = ("stereoCalibrate LM loop, flags FIX_ASPECT_RATIO+ZERO_TANGENT_DIST+USE_INTRINSIC_GUESS+SAME_FOCAL_LENGTH+"
                    "RATIONAL_MODEL+FIX_K3+FIX_K4+FIX_K5, one GPU, pairs resident in HBM; a point pair is one board point "
                    "seen by both cameras")
     return out
+
+
+def config1_block(pkg, synth, dev, steps, warmup):
+    """BASELINE configs[1]: 1000 noisy views of an asymmetric circle grid through calibrateCamera(flags = 0) -- the
+    88-point 11x8 grid the config names and the reference's literal 4x11 grid of 44 points at spacing 2
+    (monocular_circle.cpp:49-50, :35-37, :83-94).  LM loop from HBM (ms per iteration) and the whole call from host
+    buffers at cv::calibrateCamera's default criteria."""
+    out = {}
+    for label, obj, depth in (("11x8 grid, 88 points", synth.asymmetric_circles(8, 11, 12.5), (400.0, 1200.0)),
+                              ("reference 4x11 grid, 44 points", synth.asymmetric_circles(4, 11, 2.0), (40.0, 110.0))):
+        ms = synth.make_views(obj, 1000, 0xC0FFEE + 2, depth=depth)
+        cam = ms.cam
+        K0 = np.array([[cam.fx * 0.97, 0, cam.cx + 3], [0, cam.fy * 0.98, cam.cy - 2], [0, 0, 1.0]])
+        intr, mask, _ = pkg.mono_start(K0, cam.dist(5) * 0.8, 0)
+        rt0 = synth.perturbed_poses(ms.rvec, ms.tvec, 2, rot_sigma=0.01, trans_sigma=0.003 * depth[1])
+        s = pkg.Solver(obj, ms.img, device=dev)
+        r = _timed_steps(s, dict(intr=intr, imask=mask, rt=rt0), steps, warmup)
+        how = s.describe()
+        s.close()
+        pkg.calibrate_camera(obj, ms.img[:100], (640, 480), ndist=8)
+        t0 = time.perf_counter()
+        got = pkg.calibrate_camera(obj, ms.img, (640, 480), ndist=8)     # zeros(8,1), flags 0, default criteria
+        whole = (time.perf_counter() - t0) * 1e3
+        P = int(obj.shape[0])
+        out[label] = {"views": 1000, "points_per_view": P, "steps": steps, "ms_per_step": round(r["ms"][0], 4),
+                      "ms_per_step_min": round(min(r["ms"]), 4), "ms_per_step_median": round(float(np.median(r["ms"])), 4),
+                      "ms_per_step_max": round(max(r["ms"]), 4),
+                      "points_per_sec": 1000 * P * r["stats"]["jac_passes"] / (r["ms"][0] * steps * 1e-3),
+                      "jacobian_kernel": how["kernel"], "jacobian_launch_ms_in_loop": round(r["inloop_ms"], 4),
+                      "whole_call_ms": round(whole, 2), "whole_call_lm_loop_ms": round(got["device_ms"], 2),
+                      "whole_call_iters": got["iters"], "rms_px": got["rms"]}
+    out["note"] = ("1000 views is far too little work to fill the GPU (250 tiles of four views for 1024 SIMDs): these lines are "
+                   "bound by launch and host latencies, not by the kernels")
+    return out
+
+
+def config4_share_block(pkg, synth, dev, warmup, steps=10):
+    """One GPU's share of BASELINE configs[4]: 125 000 stereo pairs of a 17x12 board (204 points, so every view spans four
+    chunks of the fused kernel), fx fy cx cy k1 k2 p1 p2 k3 free in both cameras."""
+    obj = synth.chessboard(17, 12, 10.0)
+    P, N, distinct = int(obj.shape[0]), 125_000, 25_000
+    st = synth.make_stereo(obj, distinct, 0xC0FFEE + 5)
+    rep = N // distinct
+    img1, img2 = np.tile(st.img1, (rep, 1, 1)), np.tile(st.img2, (rep, 1, 1))
+    rvec, tvec = np.tile(st.rvec, (rep, 1)), np.tile(st.tvec, (rep, 1))
+    intr = np.zeros((2, 18))
+    for c, cam in enumerate((st.cam1, st.cam2)):
+        intr[c, :4] = [cam.fx * 0.98, cam.fy * 0.985, cam.cx + 2.5, cam.cy - 2.0]
+        intr[c, 4:9] = cam.dist(5) * 0.8
+    mask = np.zeros((2, 18), dtype=np.uint8)
+    mask[:, :9] = 1
+    rt0 = synth.perturbed_poses(rvec, tvec, 3, rot_sigma=0.01, trans_sigma=3.0)
+    lr0 = np.r_[st.r_lr, st.t_lr] + np.array([1e-3, -1e-3, 5e-4, 0.5, -0.2, 0.3])
+    s = pkg.Solver(obj, img1, img2, device=dev)
+    r = _timed_steps(s, dict(intr=intr, imask=mask, rt=rt0, lr=lr0), steps, min(warmup, 2), repeats=3)
+    res = s.get()
+    how = s.describe()
+    km = s.time_kernels(reps=20)
+    s.close()
+    t_jac = (r["inloop_ms"] if r["inloop_n"] > 0 else km["jac_view"]) * 1e-3
+    tf = FLOPS_JAC_PASS * how["cams_per_launch"] * N * P / t_jac / 1e12
+    return {"pairs": N, "points_per_view": P, "steps": steps, "ms_per_step": round(r["ms"][0], 4),
+            "ms_per_step_min": round(min(r["ms"]), 4), "ms_per_step_max": round(max(r["ms"]), 4),
+            "point_pairs_per_sec": N * P * r["stats"]["jac_passes"] / (r["ms"][0] * steps * 1e-3),
+            "jac_passes": r["stats"]["jac_passes"], "err_passes": r["stats"]["err_passes"],
+            "rms_px": float(np.sqrt(res["err"] / (2.0 * N * P))),
+            "roofline": {"bound": "mfma", "kernel": "k_jac_fused (16-column tile, views in four chunks of 56 points, one launch per camera)",
+                         "launch_ms": round(t_jac * 1e3, 4), "launch_ms_back_to_back": round(km["jac_view"], 4),
+                         "cameras_per_launch": how["cams_per_launch"], "achieved": round(tf, 3), "peak": PEAK_FP64_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(tf / PEAK_FP64_TFLOPS, 4), "algorithmic_flops_per_camera_point": FLOPS_JAC_PASS,
+                         "traffic": None},
+            "data": "synthetic: %d distinct pairs, each taken %d times" % (distinct, rep)}
 
 
 def whole_call(pkg, obj, ms):

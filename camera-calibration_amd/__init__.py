@@ -279,6 +279,12 @@ class Solver:
         capi.check(self._lib.ccalib_solver_counters(self._h, c))
         return dict(ahead=c[0], used=c[1], dropped=c[2])
 
+    def executed_passes(self):
+        """(Jacobian passes, residual-only passes) actually enqueued since the solver was created."""
+        c = (C.c_longlong * 2)()
+        capi.check(self._lib.ccalib_solver_executed_passes(self._h, c))
+        return int(c[0]), int(c[1])
+
     def describe(self):
         """How the Jacobian pass runs: dict(kernel ('vector' | 'fused16' | 'fused12'), cams_per_launch, grid, ncols, ncams)."""
         o = (C.c_int * 8)()

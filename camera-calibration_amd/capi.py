@@ -24,6 +24,7 @@ SYMBOLS = [
     "ccalib_solver_reduce", "ccalib_solver_time_kernels", "ccalib_lm_run",
     "ccalib_solver_init_intrinsics", "ccalib_solver_init_poses", "ccalib_solver_init_relative_pose",
     "ccalib_last_lm_trace", "ccalib_solver_describe", "ccalib_solver_profile_jac",
+    "ccalib_solver_executed_passes",
 ]
 
 OK, ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_STATE, ERR_NUMERIC = range(7)

@@ -195,6 +195,7 @@ struct ccalib_solver {
     bool run_first_jac = false;
     double drv_err = 0, committed_err = 0;  // residual sums as the driver holds them: latest trial / committed point
     long long n_ahead = 0, n_ahead_used = 0, n_ahead_dropped = 0;
+    long long n_jac_exec = 0, n_err_exec = 0;  // passes over all points that were actually enqueued (ccalib_solver_counters)
     int slot_after() const { return slot ^ 1; }
 
     // In-loop timing of the per-point Jacobian launches (ccalib_solver_profile_jac): an event before and after each
@@ -490,6 +491,7 @@ int enqueue_jac(ccalib_solver* s, int buf, double lambda_hint, int ofs, const do
                 double lambda_extra = 0.) {
     int rc = stereo_compose(s, true, buf, pose);
     if (rc) return rc;
+    s->n_jac_exec++;
     const JacLayout L = jac_layout(s);
     for (int i = 0; i < 6; i++) s->lr_jac[buf].v[i] = s->lr[i];
     if (tile12_possible(s) && !ctrl) {
@@ -943,6 +945,7 @@ int launch_trial(ccalib_solver* s, double lambda, double lambda_next, const int*
             return rc;
     } else {
         // residual pass at the trial point
+        s->n_err_exec++;
         if (!stereo_composed && (rc = stereo_compose(s, false, cur, s->d_pose_cur))) return rc;
         for (int c = 0; c < s->ncams; c++) {
             CamParams cp = cam_params(s->intr[c], s->aspect[c]);
@@ -1700,6 +1703,12 @@ int ccalib_solver_counters(ccalib_solver* s, long long out[3]) {
     return CCALIB_OK;
 }
 
+int ccalib_solver_executed_passes(ccalib_solver* s, long long out[2]) {
+    if (!s || !out) return set_error(CCALIB_ERR_ARG, "executed_passes: bad arguments");
+    out[0] = s->n_jac_exec, out[1] = s->n_err_exec;
+    return CCALIB_OK;
+}
+
 int ccalib_solver_describe(ccalib_solver* s, int out[8]) {
     if (!s || !s->started || !out) return set_error(CCALIB_ERR_STATE, "describe: a started solver and an output needed");
     for (int i = 0; i < 8; i++) out[i] = 0;
@@ -1745,6 +1754,7 @@ int ccalib_solver_eval_error(ccalib_solver* s, double* err) {
     (void)hipGetLastError();  // an error another HIP user of this thread left behind is not ours to report
     s->t_enter = std::chrono::steady_clock::now();
     int rc;
+    s->n_err_exec++;
     if ((rc = stereo_compose(s, false, s->cur, s->d_pose_cur))) return rc;
     for (int c = 0; c < s->ncams; c++) {
         CamParams cp = cam_params(s->intr[c], s->aspect[c]);

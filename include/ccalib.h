@@ -276,6 +276,13 @@ int ccalib_solver_run(ccalib_solver* s, int term_type, int max_iter, double eps,
  * MI355X it hides the host's turn-around but costs as much in device-side work, so it is kept as an option only.
  */
 int ccalib_solver_counters(ccalib_solver* s, long long out[3]);
+/*
+ * Passes over all points that the solver actually ENQUEUED since it was created: out[0] Jacobian passes (residuals +
+ * Jacobians + block accumulation), out[1] residual-only passes.  ccalib_stats counts the passes CvLevMarq asks for; a
+ * residual pass asked for at a point whose Jacobian pass was run ahead is answered from that pass and never runs, and
+ * a Jacobian pass run ahead of a step that is then rejected runs without being asked for.
+ */
+int ccalib_solver_executed_passes(ccalib_solver* s, long long out[2]);
 
 /* Results: intr ncams x 18, rt nviews x 6, lr 6 (NULL ok), err = sum of squared residuals. */
 int ccalib_solver_get(ccalib_solver* s, double* intr, double* rt, double* lr, double* err);
