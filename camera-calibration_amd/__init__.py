@@ -66,7 +66,45 @@ def _flatten(obj_views, img_views):
     return len(npts), npts, obj, img
 
 
+def _view_ptrs(views, N, width, npts=None):
+    """One pointer per view (what the ccalib_*_views entry points take) without gathering anything: returns
+    (uint64 array of N addresses, points per view, the arrays those addresses point into -- keep them alive)."""
+    if isinstance(views, np.ndarray) and views.ndim == 3:
+        a = np.ascontiguousarray(views, dtype=np.float32)
+        if a.shape[0] != N or a.shape[2] != width:
+            raise ValueError("expected %d views of %d-vectors, got %r" % (N, width, a.shape))
+        step = a.shape[1] * width * 4
+        return a.ctypes.data + np.arange(N, dtype=np.uint64) * np.uint64(step), np.full(N, a.shape[1], dtype=np.int32), a
+    if isinstance(views, np.ndarray) and views.ndim == 2:  # one board seen in every view
+        a = np.ascontiguousarray(views, dtype=np.float32)
+        if a.shape[1] != width:
+            raise ValueError("expected %d-vectors, got %r" % (width, a.shape))
+        return np.full(N, a.ctypes.data, dtype=np.uint64), np.full(N, a.shape[0], dtype=np.int32), a
+    arrs = [np.ascontiguousarray(np.asarray(v, dtype=np.float32).reshape(-1, width)) for v in views]
+    if len(arrs) != N:
+        raise ValueError("expected %d views, got %d" % (N, len(arrs)))
+    return (np.array([a.ctypes.data for a in arrs], dtype=np.uint64), np.array([len(a) for a in arrs], dtype=np.int32), arrs)
+
+
+def _views(obj_views, *img_sets):
+    """Object points + one or two sets of image points as per-view pointer arrays, checked for matching counts."""
+    N = len(img_sets[0])
+    optr, onp, okeep = _view_ptrs(obj_views, N, 3)
+    out = []
+    for img in img_sets:
+        ptr, n, keep = _view_ptrs(img, N, 2)
+        if not np.array_equal(n, onp):
+            raise ValueError("object and image point counts differ")
+        out.append((ptr, keep))
+    return N, onp, (optr, okeep), out
+
+
 TRACE_FIELDS = ("iter", "lambda_lg10_first", "lambda_lg10_accepted", "trials", "err_prev", "err", "step_norm2", "ms")
+
+
+def release_cached_memory():
+    """Returns the device blocks kept from finished calls to the driver (ccalib_release_cached_memory); bytes released."""
+    return int(capi.load().ccalib_release_cached_memory())
 
 
 def last_lm_trace():
@@ -82,7 +120,7 @@ def calibrate_camera(obj_views, img_views, size, K=None, dist=None, ndist=5, fla
                      criteria=(TERM_COUNT | TERM_EPS, 30, DBL_EPSILON), init_rt=None):
     """cv::calibrateCamera.  Returns dict(rms, K, dist, rvecs, tvecs, iters, jac_passes, err_passes, ...)."""
     lib = capi.load()
-    N, npts, obj, img = _flatten(obj_views, img_views)
+    N, npts, (obj, _ko), [(img, _ki)] = _views(obj_views, img_views)
     A = np.eye(3).reshape(-1) if K is None else np.ascontiguousarray(K, dtype=np.float64).reshape(-1).copy()
     d = np.zeros(ndist)
     if dist is not None:
@@ -92,7 +130,7 @@ def calibrate_camera(obj_views, img_views, size, K=None, dist=None, ndist=5, fla
     irt = None if init_rt is None else np.ascontiguousarray(init_rt, dtype=np.float64).reshape(N, 6)
     rms = C.c_double()
     st = capi.Stats()
-    capi.check(lib.ccalib_calibrate_camera(
+    capi.check(lib.ccalib_calibrate_camera_views(
         C.c_int(N), _p(npts), _p(obj), _p(img), C.c_int(size[0]), C.c_int(size[1]), _p(A), _p(d), C.c_int(ndist),
         _p(rv), _p(tv), C.c_int(flags), C.c_int(criteria[0]), C.c_int(criteria[1]), C.c_double(criteria[2]),
         _p(irt), C.byref(rms), C.byref(st)))
@@ -105,8 +143,7 @@ def stereo_calibrate(obj_views, img1, img2, K1, d1, K2, d2, size, flags,
                      criteria=(TERM_COUNT | TERM_EPS, 30, 1e-6), init_rt=None, init_lr=None):
     """cv::stereoCalibrate.  Distortion vectors come back with 14 entries."""
     lib = capi.load()
-    N, npts, obj, i1 = _flatten(obj_views, img1)
-    _, _, _, i2 = _flatten(obj_views, img2)
+    N, npts, (obj, _ko), [(i1, _k1), (i2, _k2)] = _views(obj_views, img1, img2)
     A1 = np.eye(3).reshape(-1) if K1 is None else np.ascontiguousarray(K1, dtype=np.float64).reshape(-1).copy()
     A2 = np.eye(3).reshape(-1) if K2 is None else np.ascontiguousarray(K2, dtype=np.float64).reshape(-1).copy()
     D1, D2 = np.zeros(14), np.zeros(14)
@@ -120,7 +157,7 @@ def stereo_calibrate(obj_views, img1, img2, K1, d1, K2, d2, size, flags,
     ilr = None if init_lr is None else np.ascontiguousarray(init_lr, dtype=np.float64).reshape(6)
     rms = C.c_double()
     st = capi.Stats()
-    capi.check(lib.ccalib_stereo_calibrate(
+    capi.check(lib.ccalib_stereo_calibrate_views(
         C.c_int(N), _p(npts), _p(obj), _p(i1), _p(i2), _p(A1), _p(D1), _p(A2), _p(D2), C.c_int(size[0]),
         C.c_int(size[1]), _p(R), _p(T), _p(E), _p(F), C.c_int(flags), C.c_int(criteria[0]), C.c_int(criteria[1]),
         C.c_double(criteria[2]), _p(irt), _p(ilr), _p(rt), C.byref(rms), C.byref(st)))
@@ -169,6 +206,12 @@ def reprojection_error(obj_views, img_views, K, dist, rvecs, tvecs, want_points=
 
 def init_camera_matrix_2d(obj_views, img_views, size, aspect=0.0):
     lib = capi.load()
+    if isinstance(obj_views, np.ndarray) and obj_views.ndim == 2 and isinstance(img_views, np.ndarray) and img_views.ndim == 3:
+        sol = Solver(obj_views, img_views)  # one board: nothing to replicate on the host
+        try:
+            return sol.init_intrinsics(size, aspect=aspect)
+        finally:
+            sol.close()
     N, npts, obj, img = _flatten(obj_views, img_views)
     A = np.zeros(9)
     capi.check(lib.ccalib_init_camera_matrix_2d(C.c_int(N), _p(npts), _p(obj), _p(img), C.c_int(size[0]),
@@ -182,11 +225,23 @@ class Solver:
     def __init__(self, obj, img1, img2=None, device=0, shared_board=True):
         lib = capi.load()
         self._lib = lib
-        N, npts, o, i1 = _flatten(obj, img1)
+        shared = bool(shared_board and isinstance(obj, np.ndarray) and np.asarray(obj).ndim == 2)
+        if shared and isinstance(img1, np.ndarray) and img1.ndim == 3:  # nothing to gather
+            N, npts = img1.shape[0], np.full(img1.shape[0], img1.shape[1], dtype=np.int32)
+            i1 = np.ascontiguousarray(img1, dtype=np.float32).reshape(-1, 2)
+            if len(obj) != img1.shape[1]:
+                raise ValueError("object and image point counts differ")
+            o = None
+        else:
+            N, npts, o, i1 = _flatten(obj, img1)
         self.nviews, self.npts, self.total = N, npts, int(npts.sum())
         self.ncams = 1 if img2 is None else 2
-        i2 = None if img2 is None else _flatten(obj, img2)[3]
-        shared = bool(shared_board and isinstance(obj, np.ndarray) and np.asarray(obj).ndim == 2)
+        i2 = None
+        if img2 is not None:
+            i2 = (np.ascontiguousarray(img2, dtype=np.float32).reshape(-1, 2) if isinstance(img2, np.ndarray) and img2.ndim == 3
+                  else np.ascontiguousarray(np.concatenate([np.asarray(v, dtype=np.float32).reshape(-1, 2) for v in img2])))
+            if len(i2) != len(i1):
+                raise ValueError("the two cameras' point counts differ")
         o_up = np.ascontiguousarray(np.asarray(obj, dtype=np.float32).reshape(-1, 3)) if shared else o
         self._h = C.c_void_p()
         capi.check(lib.ccalib_solver_create(C.byref(self._h), C.c_int(device), C.c_int(self.ncams), C.c_int(N),

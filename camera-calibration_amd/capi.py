@@ -14,7 +14,8 @@ LIB_PATH = os.environ.get("CCALIB_LIB") or os.path.join(_HERE, "libccalib.so")  
 # every symbol include/ccalib.h declares
 SYMBOLS = [
     "ccalib_last_error", "ccalib_version", "ccalib_dist_coeffs_out",
-    "ccalib_calibrate_camera", "ccalib_stereo_calibrate", "ccalib_reprojection_error",
+    "ccalib_calibrate_camera", "ccalib_stereo_calibrate", "ccalib_calibrate_camera_views", "ccalib_stereo_calibrate_views",
+    "ccalib_reprojection_error", "ccalib_release_cached_memory",
     "ccalib_reprojection_error_noalloc",
     "ccalib_init_camera_matrix_2d", "ccalib_write_mono_yaml", "ccalib_write_stereo_yaml",
     "ccalib_solver_create", "ccalib_solver_destroy", "ccalib_solver_set_start",
@@ -74,6 +75,7 @@ def load():
     lib.ccalib_last_error.restype = C.c_char_p
     lib.ccalib_version.restype = C.c_char_p
     lib.ccalib_solver_destroy.restype = None
+    lib.ccalib_release_cached_memory.restype = C.c_size_t
     _lib = lib
     return lib
 

@@ -16,6 +16,7 @@
 #include "ccalib.h"
 #include "host_rodrigues.hpp"
 #include "host_util.hpp"
+#include "solver_internal.hpp"
 
 using namespace ccalib;
 
@@ -46,6 +47,23 @@ bool views_share_board(int nviews, const int* npts, const float* obj) {
 #pragma omp parallel for schedule(static) reduction(| : differs)
     for (int i = 1; i < nviews; i++)
         if (!differs && std::memcmp(obj, obj + row * i, sizeof(float) * row) != 0) differs = 1;
+    return !differs;
+}
+
+const float* view_ptr(const HostViews& h, const std::vector<size_t>& off, int i, int fpp) {
+    return h.ptrs ? h.ptrs[i] : h.flat + (size_t)fpp * off[i];
+}
+
+// the same test over either shape of the caller's object points; views that point at one array share it trivially
+bool views_share_board(int nviews, const int* npts, const HostViews& obj) {
+    if (obj.flat) return views_share_board(nviews, npts, obj.flat);
+    for (int i = 1; i < nviews; i++)
+        if (npts[i] != npts[0]) return false;
+    const size_t bytes = sizeof(float) * 3 * npts[0];
+    int differs = 0;
+#pragma omp parallel for schedule(static) reduction(| : differs)
+    for (int i = 1; i < nviews; i++)
+        if (!differs && obj.ptrs[i] != obj.ptrs[0] && std::memcmp(obj.ptrs[0], obj.ptrs[i], bytes) != 0) differs = 1;
     return !differs;
 }
 
@@ -94,28 +112,38 @@ int ccalib_init_camera_matrix_2d(int nviews, const int* npts, const float* obj_x
     return ccalib_solver_init_intrinsics(g.s, 0, width, height, aspect, K);
 }
 
-int ccalib_calibrate_camera(int nviews, const int* npts, const float* obj_xyz, const float* img_uv, int width,
-                            int height, double* K, double* dist, int ndist, double* rvecs, double* tvecs, int flags,
-                            int term_type, int max_iter, double eps, const double* init_rt, double* rms,
-                            ccalib_stats* stats) {
-    if (nviews < 1 || !npts || !obj_xyz || !img_uv || !K || !dist || !rvecs || !tvecs || !rms)
+}  // extern "C"
+
+namespace {
+
+int calibrate_camera_impl(int nviews, const int* npts, HostViews objv, HostViews imgv, int width, int height, double* K,
+                          double* dist, int ndist, double* rvecs, double* tvecs, int flags, int term_type, int max_iter, double eps,
+                          const double* init_rt, double* rms, ccalib_stats* stats) {
+    if (nviews < 1 || !npts || (!objv.flat && !objv.ptrs) || (!imgv.flat && !imgv.ptrs) || !K || !dist || !rvecs || !tvecs || !rms)
         return set_error(CCALIB_ERR_ARG, "calibrateCamera: null argument");
     if (!(ndist == 4 || ndist == 5 || ndist == 8 || ndist == 12 || ndist == 14))
         return set_error(CCALIB_ERR_ARG, "the distortion vector must have 4, 5, 8, 12 or 14 entries (got %d)", ndist);
     int rc = check_model_flags(flags);
     if (rc) return rc;
     PhaseTimer pt;
-    size_t total = 0;
+    std::vector<size_t> off((size_t)nviews + 1, 0);
     for (int i = 0; i < nviews; i++) {
         if (npts[i] < 4) return set_error(CCALIB_ERR_ARG, "view %d has %d points (at least 4 needed)", i, npts[i]);
-        total += npts[i];
+        if (objv.ptrs && (!objv.ptrs[i] || (imgv.ptrs && !imgv.ptrs[i]))) return set_error(CCALIB_ERR_ARG, "view %d: null point array", i);
+        off[i + 1] = off[i] + npts[i];
     }
+    const size_t total = off[nviews];
     if (ndist < 8) {
         if (ndist < 5) flags |= CCALIB_FIX_K3;
         flags |= CCALIB_FIX_K4 | CCALIB_FIX_K5 | CCALIB_FIX_K6;
     }
-    const float* obj = obj_xyz;
-    std::vector<float> flattened;  // only when the rig's Z has to be cleared
+    // one board seen in every view (the reference's case: objectPoints.resize(n, objectPoints[0])) is found first:
+    // everything below then looks at its few dozen points instead of at every view's copy
+    const bool shared = views_share_board(nviews, npts, objv);
+    pt.lap("shared-board test");
+    const int nobjviews = shared ? 1 : nviews;
+    std::vector<float> flattened;             // only when the rig's Z has to be cleared
+    std::vector<const float*> flat_ptrs;
     double A[9], k[14] = {0}, aspect = 0;
     std::memcpy(A, K, sizeof(A));
     if (flags & CCALIB_USE_INTRINSIC_GUESS) {
@@ -129,18 +157,34 @@ int ccalib_calibrate_camera(int nviews, const int* npts, const float* obj_xyz, c
         if (flags & CCALIB_FIX_ASPECT_RATIO) aspect = A[0] / A[4];
         for (int i = 0; i < ndist; i++) k[i] = dist[i];
     } else {
+        // mean and spread of Z over all object points (a shared board counts once per view: same numbers)
         double mean = 0, sq = 0;
-#pragma omp parallel for schedule(static) reduction(+ : mean)
-        for (size_t i = 0; i < total; i++) mean += obj[3 * i + 2];
-        mean /= (double)total;
-#pragma omp parallel for schedule(static) reduction(+ : sq)
-        for (size_t i = 0; i < total; i++) sq += (obj[3 * i + 2] - mean) * (obj[3 * i + 2] - mean);
-        if (std::fabs(mean) > 1e-5 || std::sqrt(sq / (double)total) > 1e-5)
+#pragma omp parallel for schedule(static) reduction(+ : mean) if (nobjviews > 64)
+        for (int i = 0; i < nobjviews; i++) {
+            const float* o = view_ptr(objv, off, i, 3);
+            for (int p = 0; p < npts[i]; p++) mean += o[3 * p + 2];
+        }
+        const double nobjpts = shared ? (double)npts[0] : (double)total;
+        mean /= nobjpts;
+#pragma omp parallel for schedule(static) reduction(+ : sq) if (nobjviews > 64)
+        for (int i = 0; i < nobjviews; i++) {
+            const float* o = view_ptr(objv, off, i, 3);
+            for (int p = 0; p < npts[i]; p++) sq += (o[3 * p + 2] - mean) * (o[3 * p + 2] - mean);
+        }
+        if (std::fabs(mean) > 1e-5 || std::sqrt(sq / nobjpts) > 1e-5)
             return set_error(CCALIB_ERR_ARG, "for non-planar calibration rigs the initial intrinsic matrix must be specified");
-        if (sq != 0 || mean != 0) {
-            flattened.assign(obj_xyz, obj_xyz + 3 * total);
-            for (size_t i = 0; i < total; i++) flattened[3 * i + 2] = 0.f;
-            obj = flattened.data();
+        if (sq != 0 || mean != 0) {  // OpenCV clears the Z it has just found negligible
+            const size_t nflat = shared ? (size_t)npts[0] : total;
+            flattened.resize(3 * nflat);
+            flat_ptrs.resize(nobjviews);
+            for (int i = 0; i < nobjviews; i++) {
+                float* d = flattened.data() + 3 * off[i];
+                std::memcpy(d, view_ptr(objv, off, i, 3), sizeof(float) * 3 * npts[i]);
+                for (int p = 0; p < npts[i]; p++) d[3 * p + 2] = 0.f;
+                flat_ptrs[i] = d;
+            }
+            if (shared) flat_ptrs.assign(nviews, flattened.data());
+            objv = HostViews{nullptr, flat_ptrs.data()};
         }
         if (flags & CCALIB_FIX_ASPECT_RATIO) aspect = A[0] / A[4];
     }
@@ -148,10 +192,8 @@ int ccalib_calibrate_camera(int nviews, const int* npts, const float* obj_xyz, c
         return set_error(CCALIB_ERR_ARG, "the specified aspect ratio (= cameraMatrix[0][0] / cameraMatrix[1][1]) is incorrect");
     // the points go to the device once; initialisation and the LM loop both run there
     pt.lap("argument checks");
-    bool shared = views_share_board(nviews, npts, obj);
-    pt.lap("shared-board test");
     SolverGuard g;
-    if ((rc = ccalib_solver_create(&g.s, 0, 1, nviews, npts, obj, shared ? 1 : 0, img_uv, nullptr))) return rc;
+    if ((rc = solver_create_views(&g.s, 0, 1, nviews, npts, objv, shared ? 1 : 0, imgv, HostViews{nullptr, nullptr}))) return rc;
     pt.lap("solver create + upload");
     if (!(flags & CCALIB_USE_INTRINSIC_GUESS) && (rc = ccalib_solver_init_intrinsics(g.s, 0, width, height, aspect, A))) return rc;
     pt.lap("intrinsic seed");
@@ -166,7 +208,6 @@ int ccalib_calibrate_camera(int nviews, const int* npts, const float* obj_xyz, c
     // starting poses: the caller's, or cvFindExtrinsicCameraParams2 per view (left on the device)
     if (!init_rt && (rc = ccalib_solver_init_poses(g.s, 0, A, k, nullptr))) return rc;
     pt.lap("pose initialisation");
-    std::vector<double> rt((size_t)6 * nviews);
     double asp[1] = {(flags & CCALIB_FIX_ASPECT_RATIO) ? aspect : 0.};
     if ((rc = ccalib_solver_set_start(g.s, intr, mask, asp, 0, init_rt, nullptr))) return rc;
     ccalib_stats st;
@@ -174,25 +215,47 @@ int ccalib_calibrate_camera(int nviews, const int* npts, const float* obj_xyz, c
     if ((rc = ccalib_solver_run(g.s, term_type, max_iter, eps, method, &st))) return rc;
     pt.lap("set_start + LM loop");
     double err = 0;
-    if ((rc = ccalib_solver_get(g.s, intr, rt.data(), nullptr, &err))) return rc;
+    if ((rc = ccalib_solver_get(g.s, intr, nullptr, nullptr, &err))) return rc;
+    if ((rc = solver_get_poses_split(g.s, rvecs, tvecs))) return rc;
     K[0] = intr[0], K[1] = 0, K[2] = intr[2], K[3] = 0, K[4] = intr[1], K[5] = intr[3], K[6] = 0, K[7] = 0, K[8] = 1;
     for (int i = 0; i < ndist; i++) dist[i] = intr[4 + i];
-    for (int i = 0; i < nviews; i++) {
-        std::memcpy(rvecs + 3 * i, rt.data() + 6 * i, 3 * sizeof(double));
-        std::memcpy(tvecs + 3 * i, rt.data() + 6 * i + 3, 3 * sizeof(double));
-    }
     *rms = std::sqrt(err / (double)total);
     if (stats) *stats = st;
     pt.lap("download");
     return CCALIB_OK;
 }
 
-int ccalib_stereo_calibrate(int nviews, const int* npts, const float* obj_xyz, const float* img1_uv,
-                            const float* img2_uv, double* K1, double* dist1, double* K2, double* dist2, int width,
-                            int height, double* R, double* T, double* E, double* F, int flags, int term_type,
-                            int max_iter, double eps, const double* init_rt, const double* init_lr, double* rt_out,
-                            double* rms, ccalib_stats* stats) {
-    if (nviews < 1 || !npts || !obj_xyz || !img1_uv || !img2_uv || !K1 || !K2 || !dist1 || !dist2 || !R || !T || !rms)
+}  // namespace
+
+extern "C" {
+
+int ccalib_calibrate_camera(int nviews, const int* npts, const float* obj_xyz, const float* img_uv, int width,
+                            int height, double* K, double* dist, int ndist, double* rvecs, double* tvecs, int flags,
+                            int term_type, int max_iter, double eps, const double* init_rt, double* rms,
+                            ccalib_stats* stats) {
+    return calibrate_camera_impl(nviews, npts, HostViews{obj_xyz, nullptr}, HostViews{img_uv, nullptr}, width, height, K, dist, ndist,
+                                 rvecs, tvecs, flags, term_type, max_iter, eps, init_rt, rms, stats);
+}
+
+int ccalib_calibrate_camera_views(int nviews, const int* npts, const float* const* obj_views, const float* const* img_views,
+                                  int width, int height, double* K, double* dist, int ndist, double* rvecs, double* tvecs,
+                                  int flags, int term_type, int max_iter, double eps, const double* init_rt, double* rms,
+                                  ccalib_stats* stats) {
+    return calibrate_camera_impl(nviews, npts, HostViews{nullptr, obj_views}, HostViews{nullptr, img_views}, width, height, K, dist,
+                                 ndist, rvecs, tvecs, flags, term_type, max_iter, eps, init_rt, rms, stats);
+}
+
+}  // extern "C"
+
+namespace {
+
+int stereo_calibrate_impl(int nviews, const int* npts, HostViews objv, HostViews img1v, HostViews img2v, double* K1, double* dist1,
+                          double* K2, double* dist2, int width, int height, double* R, double* T, double* E, double* F, int flags,
+                          int term_type, int max_iter, double eps, const double* init_rt, const double* init_lr, double* rt_out,
+                          double* rms, ccalib_stats* stats) {
+    auto given_views = [](const HostViews& h) { return h.flat || h.ptrs; };
+    if (nviews < 1 || !npts || !given_views(objv) || !given_views(img1v) || !given_views(img2v) || !K1 || !K2 || !dist1 || !dist2 ||
+        !R || !T || !rms)
         return set_error(CCALIB_ERR_ARG, "stereoCalibrate: null argument");
     int rc = check_model_flags(flags);
     if (rc) return rc;
@@ -201,9 +264,11 @@ int ccalib_stereo_calibrate(int nviews, const int* npts, const float* obj_xyz, c
     size_t total = 0;
     for (int i = 0; i < nviews; i++) {
         if (npts[i] < 4) return set_error(CCALIB_ERR_ARG, "view %d has %d points (at least 4 needed)", i, npts[i]);
+        for (const HostViews* h : {&objv, &img1v, &img2v})
+            if (h->ptrs && !h->ptrs[i]) return set_error(CCALIB_ERR_ARG, "view %d: null point array", i);
         total += npts[i];
     }
-    const float* imgs[2] = {img1_uv, img2_uv};
+    const HostViews imgs[2] = {img1v, img2v};
     double* Kio[2] = {K1, K2};
     double* dio[2] = {dist1, dist2};
     double Ak[2][9] = {{0}}, dk[2][14] = {{0}};
@@ -217,9 +282,8 @@ int ccalib_stereo_calibrate(int nviews, const int* npts, const float* obj_xyz, c
             // OpenCV calibrates each camera on its own first
             std::vector<double> rv((size_t)3 * nviews), tv((size_t)3 * nviews);
             double r0;
-            if ((rc = ccalib_calibrate_camera(nviews, npts, obj_xyz, imgs[c], width, height, Ak[c], dk[c], 14, rv.data(),
-                                              tv.data(), flags, CCALIB_TERM_COUNT | CCALIB_TERM_EPS, 30, DBL_EPSILON,
-                                              nullptr, &r0, nullptr)))
+            if ((rc = calibrate_camera_impl(nviews, npts, objv, imgs[c], width, height, Ak[c], dk[c], 14, rv.data(), tv.data(),
+                                            flags, CCALIB_TERM_COUNT | CCALIB_TERM_EPS, 30, DBL_EPSILON, nullptr, &r0, nullptr)))
                 return rc;
         }
     }
@@ -254,9 +318,9 @@ int ccalib_stereo_calibrate(int nviews, const int* npts, const float* obj_xyz, c
         }
         if (flags & CCALIB_FIX_INTRINSIC) std::memset(mask, 0, 36);  // intrinsics are not parameters at all
     }
-    bool shared = views_share_board(nviews, npts, obj_xyz);
+    bool shared = views_share_board(nviews, npts, objv);
     SolverGuard g;
-    if ((rc = ccalib_solver_create(&g.s, 0, 2, nviews, npts, obj_xyz, shared ? 1 : 0, img1_uv, img2_uv))) return rc;
+    if ((rc = solver_create_views(&g.s, 0, 2, nviews, npts, objv, shared ? 1 : 0, img1v, img2v))) return rc;
     double lr[6];
     const bool given = init_rt && init_lr;
     if (given) {
@@ -320,6 +384,30 @@ int ccalib_stereo_calibrate(int nviews, const int* npts, const float* obj_xyz, c
     *rms = std::sqrt(err / (2. * (double)total));
     if (stats) *stats = st;
     return CCALIB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ccalib_stereo_calibrate(int nviews, const int* npts, const float* obj_xyz, const float* img1_uv,
+                            const float* img2_uv, double* K1, double* dist1, double* K2, double* dist2, int width,
+                            int height, double* R, double* T, double* E, double* F, int flags, int term_type,
+                            int max_iter, double eps, const double* init_rt, const double* init_lr, double* rt_out,
+                            double* rms, ccalib_stats* stats) {
+    return stereo_calibrate_impl(nviews, npts, HostViews{obj_xyz, nullptr}, HostViews{img1_uv, nullptr}, HostViews{img2_uv, nullptr},
+                                 K1, dist1, K2, dist2, width, height, R, T, E, F, flags, term_type, max_iter, eps, init_rt, init_lr,
+                                 rt_out, rms, stats);
+}
+
+int ccalib_stereo_calibrate_views(int nviews, const int* npts, const float* const* obj_views, const float* const* img1_views,
+                                  const float* const* img2_views, double* K1, double* dist1, double* K2, double* dist2, int width,
+                                  int height, double* R, double* T, double* E, double* F, int flags, int term_type, int max_iter,
+                                  double eps, const double* init_rt, const double* init_lr, double* rt_out, double* rms,
+                                  ccalib_stats* stats) {
+    return stereo_calibrate_impl(nviews, npts, HostViews{nullptr, obj_views}, HostViews{nullptr, img1_views},
+                                 HostViews{nullptr, img2_views}, K1, dist1, K2, dist2, width, height, R, T, E, F, flags, term_type,
+                                 max_iter, eps, init_rt, init_lr, rt_out, rms, stats);
 }
 
 }  // extern "C"

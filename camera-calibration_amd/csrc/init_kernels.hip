@@ -497,19 +497,34 @@ __device__ __forceinline__ float2 undistort(float2 m, const CamParams& cp) {
 
 }  // namespace
 
+// Sum over the L consecutive lanes that share a view, returned in all of them: the butterfly adds the same two
+// numbers in both lanes of a pair, so every lane of the group ends up with the same bits and takes the same branches.
+template <int L>
+__device__ __forceinline__ double group_sum(double v) {
+    static_assert(L == 1 || L == 2 || L == 4 || L == 8 || L == 16 || L == 64, "lanes per view");
+    if (L == 64) return wave_sum(v);
+    if (L >= 2) v += dpp_move<0xB1>(v);    // quad_perm [1,0,3,2]
+    if (L >= 4) v += dpp_move<0x4E>(v);    // quad_perm [2,3,0,1]
+    if (L >= 8) v += dpp_move<0x141>(v);   // row_half_mirror: lane i <-> 7 - i of each half row
+    if (L >= 16) v += dpp_move<0x140>(v);  // row_mirror: lane i <-> 15 - i of each row
+    return v;
+}
+
 // CvLevMarq(6 parameters) with criteria (COUNT + EPS, 20, FLT_EPSILON) on the reprojection error of one view:
-// the refinement at the end of cvFindExtrinsicCameraParams2.  Most views are done after five iterations, one
-// in a hundred needs all twenty, and a wavefront runs as long as its slowest lane: so the loop can be left
-// at an iteration boundary (stop_at) with its state -- pose, damping exponent, iteration count, residual norm --
-// and picked up later by a wavefront filled with such views only (fresh = false).  Returns true when done.
-template <class M, class Obj>
+// the refinement at the end of cvFindExtrinsicCameraParams2.  L lanes share a view: lane `sub` of the group takes
+// points sub, sub + L, ... and the sums over points are completed with group_sum, so all L lanes carry the same
+// pose and state.  Most views are done after five iterations, one in a hundred needs all twenty, and a wavefront
+// runs as long as its slowest view: so the loop can be left at an iteration boundary (stop_at) with its state --
+// pose, damping exponent, iteration count, residual norm -- and picked up later by a wavefront filled with such
+// views only (fresh = false).  Returns true when done.
+template <class M, int L, class Obj>
 __device__ bool refine_pose(int n, Obj obj, const float2* irow, const CamParams& cp, double (&ps)[6], int& lambdaLg10,
-                            int& iters, double& errNorm, bool fresh, int stop_at) {
+                            int& iters, double& errNorm, bool fresh, int stop_at, int sub) {
     double JtJ[21], Jte[6], prev[6];
     auto eval_err = [&]() {
         double R[9], e2 = 0;
         rodrigues<false>(ps, R, nullptr);
-        for (int p = 0; p < n; p++) {
+        for (int p = sub; p < n; p += L) {
             float3 o = obj(p);
             float2 m = irow[p];
             double X = o.x, Y = o.y, Z = o.z;
@@ -520,7 +535,7 @@ __device__ bool refine_pose(int n, Obj obj, const float2* irow, const CamParams&
             point_eval<M, false, false>(Xc, Yc, Zc, (double)m.x, (double)m.y, cp, o2);
             e2 += o2.ex * o2.ex + o2.ey * o2.ey;
         }
-        return e2;
+        return group_sum<L>(e2);
     };
     auto eval_jac = [&]() {
         const PoseConst q = pose_const(ps);
@@ -529,7 +544,7 @@ __device__ bool refine_pose(int n, Obj obj, const float2* irow, const CamParams&
         for (int k = 0; k < 21; k++) JtJ[k] = 0;
 #pragma unroll
         for (int k = 0; k < 6; k++) Jte[k] = 0;
-        for (int p = 0; p < n; p++) {
+        for (int p = sub; p < n; p += L) {
             float3 o = obj(p);
             float2 m = irow[p];
             PointOut<M> o2;
@@ -543,16 +558,20 @@ __device__ bool refine_pose(int n, Obj obj, const float2* irow, const CamParams&
             }
             e2 += o2.ex * o2.ex + o2.ey * o2.ey;
         }
-        return e2;
+#pragma unroll
+        for (int k = 0; k < 21; k++) JtJ[k] = group_sum<L>(JtJ[k]);
+#pragma unroll
+        for (int k = 0; k < 6; k++) Jte[k] = group_sum<L>(Jte[k]);
+        return group_sum<L>(e2);
     };
     auto step = [&]() {
         double lambda = exp(lambdaLg10 * 2.302585092994046);
-        double L[21], invd[6], x[6];
+        double Lc[21], invd[6], x[6];
 #pragma unroll
         for (int k = 0; k < 6; k++) x[k] = Jte[k];
-        bool pd = chol6(JtJ, lambda, L, invd);
-        chol6_fwd(L, invd, x);
-        chol6_bwd(L, invd, x);
+        bool pd = chol6(JtJ, lambda, Lc, invd);
+        chol6_fwd(Lc, invd, x);
+        chol6_bwd(Lc, invd, x);
 #pragma unroll
         for (int k = 0; k < 6; k++) ps[k] = prev[k] - (pd ? x[k] : 0.);
     };
@@ -581,7 +600,6 @@ __device__ bool refine_pose(int n, Obj obj, const float2* irow, const CamParams&
 // ---- cvFindExtrinsicCameraParams2 for every view ---------------------------------------------
 template <bool RAT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_init_pose(InitArgs a, CamParams cp, double* __restrict__ pose, int* __restrict__ status, Parked parked) {
-    using M = Model<0u, false, RAT>;
     const int lane = threadIdx.x;
     const int v0 = blockIdx.x * a.VPB;
     const int nv = min(a.VPB, a.nviews - v0);
@@ -653,45 +671,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         ps[3] = ps[4] = ps[5] = 0;
     }
     rodrigues_m2v_polar(Rm, ps);
-    // the raw image points come back for the refinement
-    __syncthreads();
-    stage_img(a, st, view_of, nv);
-    __syncthreads();
-
-    int lambdaLg10 = -3, iters = 0;
-    double errNorm = 0;
-    const bool done = refine_pose<M>(n, obj, irow, cp, ps, lambdaLg10, iters, errNorm, true, a.cut) || !planar;
     if (live) {
-        if (done) {
 #pragma unroll
-            for (int k = 0; k < 6; k++) pose[6 * (size_t)v + k] = planar ? ps[k] : 0.;
-            status[v] = planar ? 0 : 1;
-        } else {  // parked: a later wavefront of slow views takes it from here
-            int slot = atomicAdd(parked.count, 1);
-            parked.view[slot] = v;
-            double* d = parked.state + kParkedDoubles * (size_t)slot;
-#pragma unroll
-            for (int k = 0; k < 6; k++) d[k] = ps[k];
-            d[6] = errNorm, d[7] = lambdaLg10, d[8] = iters;
-        }
+        for (int k = 0; k < 6; k++) pose[6 * (size_t)v + k] = planar ? ps[k] : 0.;
+        status[v] = planar ? 0 : 1;
     }
 }
 
-// The views k_init_pose parked, 64 to a wavefront: their points are gathered into the stage and the
-// refinement runs on to its end.  The grid covers the worst case; workgroups past the parked count leave.
-template <bool RAT>
-__global__ __launch_bounds__(64) void k_init_pose_resume(InitArgs a, CamParams cp, double* __restrict__ pose,
-                                                         int* __restrict__ status, Parked parked) {
+// The refinement of the poses k_init_pose left (RESUME = false: every view, parked after a.cut iterations if still
+// running) or of the views an earlier launch parked (RESUME = true: gathered, run to the end).  L lanes per view,
+// 64 / L views per wavefront (a.VPB of them staged; lanes past that shadow the workgroup's first view and store
+// nothing).  The resuming grid covers the worst case; workgroups past the parked count leave.
+#ifndef CCALIB_REFINE_WAVES
+#define CCALIB_REFINE_WAVES 3  // wavefronts per SIMD the register budget of the refinement is set for
+#endif
+template <bool RAT, int L, bool RESUME>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CCALIB_REFINE_WAVES, CCALIB_REFINE_WAVES))) void k_refine_pose(InitArgs a, CamParams cp, double* __restrict__ pose, int* __restrict__ status,
+                                                    Parked parked) {
     using M = Model<0u, false, RAT>;
-    const int lane = threadIdx.x;
-    const int total = *parked.count;
+    const int lane = threadIdx.x, sub = lane % L, slot = lane / L;
+    const int total = RESUME ? *parked.count : a.nviews;
     const int j0 = blockIdx.x * a.VPB;
     if (j0 >= total) return;
     const int nv = min(a.VPB, total - j0);
-    const Stage st = stage_layout(a, true);
-    const bool live = lane < nv;
-    const int row = live ? lane : 0;
-    auto view_of = [&](int j) { return parked.view[j0 + j]; };
+    const Stage st = stage_layout(a, false);
+    const bool live = slot < nv;
+    const int row = live ? slot : 0;
+    auto view_of = [&](int j) { return RESUME ? parked.view[j0 + j] : j0 + j; };
     const int v = view_of(row);
     const int n = a.off[v + 1] - a.off[v];
     stage_img(a, st, view_of, nv);
@@ -700,17 +706,25 @@ __global__ __launch_bounds__(64) void k_init_pose_resume(InitArgs a, CamParams c
     const float* ob = a.shared_board ? st.obj : st.obj + row * 3 * st.PS;
     auto obj = [&](int p) { return make_float3(ob[3 * p], ob[3 * p + 1], ob[3 * p + 2]); };
     const float2* irow = st.img + row * st.PS;
-    const double* d = parked.state + kParkedDoubles * (size_t)(j0 + row);
+    const double* d = RESUME ? parked.state + kParkedDoubles * (size_t)(j0 + row) : pose + 6 * (size_t)v;
     double ps[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) ps[k] = d[k];
-    double errNorm = d[6];
-    int lambdaLg10 = (int)d[7], iters = (int)d[8];
-    refine_pose<M>(n, obj, irow, cp, ps, lambdaLg10, iters, errNorm, false, 1 << 30);
-    if (live) {
+    double errNorm = RESUME ? d[6] : 0.;
+    int lambdaLg10 = RESUME ? (int)d[7] : -3, iters = RESUME ? (int)d[8] : 0;
+    if (!RESUME && status[v] != 0) return;  // no planar rig in this view: the zero pose stands (all L lanes leave together)
+    const bool done = refine_pose<M, L>(n, obj, irow, cp, ps, lambdaLg10, iters, errNorm, !RESUME, RESUME ? 1 << 30 : a.cut, sub);
+    if (!live || sub != 0) return;
+    if (done) {
 #pragma unroll
         for (int k = 0; k < 6; k++) pose[6 * (size_t)v + k] = ps[k];
-        status[v] = 0;
+    } else {  // parked: a later wavefront of slow views takes it from here
+        int at = atomicAdd(parked.count, 1);
+        parked.view[at] = v;
+        double* o = parked.state + kParkedDoubles * (size_t)at;
+#pragma unroll
+        for (int k = 0; k < 6; k++) o[k] = ps[k];
+        o[6] = errNorm, o[7] = lambdaLg10, o[8] = iters;
     }
 }
 
@@ -812,16 +826,59 @@ bool init_geometry(InitArgs& a, bool with_src) {
     return false;
 }
 
+// Lanes per view in the pose refinement.  Four: 16 views to a wavefront, so 100 000 views make 6250 wavefronts (six
+// per SIMD, all resident) instead of 1563 that leave most SIMDs with one wavefront and nothing to hide latency with.
+constexpr int kRefineLanes = 4;
+// ... and in the second round, which takes the few views still running after a.cut iterations to the end.  What is
+// left there is a chain of up to 14 dependent iterations per view, so more lanes per view shorten it (16 lanes: 0.27
+// instead of 0.37 ms at 100 000 views) -- but the sums over points then run in another order than in the first round,
+// the last bits of a resumed view depend on where it was parked, and a refinement that stops one iteration earlier or
+// later moves a starting pose by 1e-7.  With the same lane count in both rounds a view's result does not depend on
+// a.cut at all.  CCALIB_RESUME_LANES = 8, 16 or 64 is there to measure with.
+constexpr int kResumeLanes = kRefineLanes;
+
+template <bool RAT, int L>
+static void launch_resume(const InitArgs& a, const CamParams& cp, double* pose, int* status, const Parked& parked, hipStream_t st) {
+    InitArgs r = a;
+    for (r.VPB = std::min(a.VPB, 64 / L);; r.VPB--) {
+        r.lds_bytes = (unsigned)(sizeof(float) * init_lds_floats(a.shared_board != 0, a.board_np, a.PS, r.VPB, false));
+        if (r.lds_bytes <= 64 * 1024 || r.VPB == 1) break;
+    }
+    // the worst case (every view parked) sizes the grid; workgroups past the parked count leave at once
+    k_refine_pose<RAT, L, true><<<dim3((a.nviews + r.VPB - 1) / r.VPB), dim3(64), r.lds_bytes, st>>>(r, cp, pose, status, parked);
+}
+template <bool RAT>
+static void launch_resume_any(const InitArgs& a, const CamParams& cp, double* pose, int* status, const Parked& parked,
+                              hipStream_t st) {
+    int L = kResumeLanes;
+    if (const char* e = std::getenv("CCALIB_RESUME_LANES")) L = std::atoi(e);
+    switch (L) {
+        case 8: return launch_resume<RAT, 8>(a, cp, pose, status, parked, st);
+        case 16: return launch_resume<RAT, 16>(a, cp, pose, status, parked, st);
+        case 64: return launch_resume<RAT, 64>(a, cp, pose, status, parked, st);
+        default: return launch_resume<RAT, kRefineLanes>(a, cp, pose, status, parked, st);
+    }
+}
+
 void launch_init_pose(const InitArgs& a, const CamParams& cp, bool rational, double* pose, int* status, const Parked& parked,
                       hipStream_t st) {
     int grid = (a.nviews + a.VPB - 1) / a.VPB;
     (void)hipMemsetAsync(parked.count, 0, sizeof(int), st);
+    // the refinement stages no homography source points and fewer views per workgroup
+    InitArgs r = a;
+    for (r.VPB = std::min(a.VPB, 64 / kRefineLanes);; r.VPB--) {  // a.VPB views with source points fit, so this ends at >= 1
+        r.lds_bytes = (unsigned)(sizeof(float) * init_lds_floats(a.shared_board != 0, a.board_np, a.PS, r.VPB, false));
+        if (r.lds_bytes <= 64 * 1024 || r.VPB == 1) break;
+    }
+    int rgrid = (a.nviews + r.VPB - 1) / r.VPB;
     if (rational) {
         k_init_pose<true><<<dim3(grid), dim3(64), a.lds_bytes, st>>>(a, cp, pose, status, parked);
-        k_init_pose_resume<true><<<dim3(grid), dim3(64), a.lds_bytes, st>>>(a, cp, pose, status, parked);
+        k_refine_pose<true, kRefineLanes, false><<<dim3(rgrid), dim3(64), r.lds_bytes, st>>>(r, cp, pose, status, parked);
+        launch_resume_any<true>(a, cp, pose, status, parked, st);
     } else {
         k_init_pose<false><<<dim3(grid), dim3(64), a.lds_bytes, st>>>(a, cp, pose, status, parked);
-        k_init_pose_resume<false><<<dim3(grid), dim3(64), a.lds_bytes, st>>>(a, cp, pose, status, parked);
+        k_refine_pose<false, kRefineLanes, false><<<dim3(rgrid), dim3(64), r.lds_bytes, st>>>(r, cp, pose, status, parked);
+        launch_resume_any<false>(a, cp, pose, status, parked, st);
     }
 }
 

@@ -18,13 +18,17 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
+
+#include <omp.h>
 
 #include "ccalib.h"
 #include "host_util.hpp"
 #include "init_kernels.hpp"
 #include "kernels.hpp"
 #include "lm_step.hpp"
+#include "solver_internal.hpp"
 #include "stereo_kernels.hpp"
 
 using namespace ccalib;
@@ -65,6 +69,15 @@ struct ccalib_solver {
     bool use_fused = true;
     unsigned lds_bytes = 0;
     hipStream_t stream = nullptr;
+    // Device memory comes from two allocations carved into pieces: `arena` (everything whose size the view table fixes:
+    // points, poses, records, reduction buffers, initialisation state) and `arena2` (what depends on the column set:
+    // the per-view blocks and the partial-result arenas); one pinned block holds both slots' host-visible sums and
+    // flags.  A solver is created and destroyed inside every cv::calibrateCamera-shaped call, and each hipMalloc /
+    // hipFree costs 0.05-0.3 ms.
+    char* arena = nullptr;
+    char* arena2 = nullptr;
+    size_t arena_bytes = 0, arena2_bytes = 0, pinned_bytes = 0;
+    char* pinned = nullptr;
     float* d_obj = nullptr;
     int* d_off = nullptr;
     float2* d_img[2] = {nullptr, nullptr};
@@ -85,6 +98,7 @@ struct ccalib_solver {
     int* d_status = nullptr;
     int* d_parked_view = nullptr;      // views the first pose kernel parked (count in entry nviews)
     double* d_parked_state = nullptr;
+    double* d_init_part = nullptr;     // partial sums of the intrinsic initialisation (5 per workgroup)
     double* d_pose_init1 = nullptr;  // stereo: camera-1 planar poses until the relative pose has been taken
     bool poses_ready[2] = {false, false};
     bool pc_fresh = false;   // d_pc matches d_pose_cur
@@ -1168,7 +1182,189 @@ extern "C" {
 
 int ccalib_solver_create(ccalib_solver** out, int device, int ncams, int nviews, const int* npts,
                          const float* obj_xyz, int shared_board, const float* img1_uv, const float* img2_uv) {
-    if (!out || !npts || !obj_xyz || !img1_uv || nviews < 1 || (ncams != 1 && ncams != 2) || (ncams == 2 && !img2_uv))
+    if (!obj_xyz || !img1_uv || (ncams == 2 && !img2_uv)) return set_error(CCALIB_ERR_ARG, "ccalib_solver_create: bad arguments");
+    return solver_create_views(out, device, ncams, nviews, npts, HostViews{obj_xyz, nullptr}, shared_board,
+                               HostViews{img1_uv, nullptr}, HostViews{img2_uv, nullptr});
+}
+
+}  // extern "C"
+
+namespace ccalib {
+
+namespace {
+
+// Blocks a destroyed solver hands back, kept for the next one: cv::calibrateCamera-shaped callers create and destroy
+// a solver per call, and hipMalloc + hipFree of its two arenas, the pinned block and the stream cost about a
+// millisecond per call (hipFree also waits for the whole device).  Device blocks are kept per device up to
+// CCALIB_POOL_MB megabytes in total (default 1024, 0 = keep nothing) and reused when the request fills at least a
+// quarter of the block; ccalib_release_cached_memory() returns everything to the driver.
+struct BlockPool {
+    enum Kind { kDevice, kPinned, kStream };
+    struct Block {
+        int device;
+        Kind kind;
+        void* p;
+        size_t bytes;
+    };
+    std::mutex mu;
+    std::vector<Block> free_blocks;
+    size_t cached_device_bytes = 0;
+    size_t cap() {
+        static const size_t c = [] {
+            const char* e = std::getenv("CCALIB_POOL_MB");
+            return (size_t)(e ? std::max(0, std::atoi(e)) : 1024) << 20;
+        }();
+        return c;
+    }
+    void* take(int device, Kind kind, size_t bytes, size_t* got) {
+        std::lock_guard<std::mutex> lock(mu);
+        int best = -1;
+        for (int i = 0; i < (int)free_blocks.size(); i++) {
+            const Block& b = free_blocks[i];
+            if (b.device != device || b.kind != kind || b.bytes < bytes || b.bytes / 4 > bytes) continue;
+            if (best < 0 || b.bytes < free_blocks[best].bytes) best = i;
+        }
+        if (best < 0) return nullptr;
+        Block b = free_blocks[best];
+        free_blocks.erase(free_blocks.begin() + best);
+        if (b.kind == kDevice) cached_device_bytes -= b.bytes;
+        if (got) *got = b.bytes;
+        return b.p;
+    }
+    static void release(const Block& b) {
+        if (b.kind == kDevice) (void)hipFree(b.p);
+        if (b.kind == kPinned) (void)hipHostFree(b.p);
+        if (b.kind == kStream) (void)hipStreamDestroy((hipStream_t)b.p);
+    }
+    // the caller has made sure nothing on the device still uses the block
+    void give(int device, Kind kind, void* p, size_t bytes) {
+        if (!p) return;
+        Block b{device, kind, p, bytes};
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            const bool fits = kind != kDevice || cached_device_bytes + bytes <= cap();
+            if (cap() > 0 && fits && free_blocks.size() < 64) {
+                free_blocks.push_back(b);
+                if (kind == kDevice) cached_device_bytes += bytes;
+                return;
+            }
+        }
+        release(b);
+    }
+    size_t trim() {
+        std::vector<Block> all;
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            all.swap(free_blocks);
+            cached_device_bytes = 0;
+        }
+        size_t n = 0;
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        for (const Block& b : all) {
+            (void)hipSetDevice(b.device);
+            release(b);
+            if (b.kind == kDevice) n += b.bytes;
+        }
+        if (cur >= 0) (void)hipSetDevice(cur);
+        return n;
+    }
+};
+BlockPool g_pool;
+
+int pool_device_alloc(int device, size_t bytes, char** out, size_t* got) {
+    *got = bytes;
+    if (void* p = g_pool.take(device, BlockPool::kDevice, bytes, got)) {
+        *out = static_cast<char*>(p);
+        return CCALIB_OK;
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipErrorOutOfMemory && g_pool.trim() > 0) e = hipMalloc(out, bytes);  // the cache gives way to a live request
+    HIP_TRY(e);
+    return CCALIB_OK;
+}
+
+// Hands out 256-byte aligned pieces of one allocation; with a null base it only adds the sizes up.
+struct Carver {
+    char* base;
+    size_t used = 0;
+    template <class T>
+    T* take(size_t n) {
+        T* p = base ? reinterpret_cast<T*>(base + used) : nullptr;
+        used += (n * sizeof(T) + 255) & ~(size_t)255;
+        return p;
+    }
+};
+
+// Pinned staging for uploads, shared by every solver of the process (created on first use, kept): two buffers, so
+// that the host fills one while the copy engine drains the other.
+struct Staging {
+    std::mutex mu;
+    float* buf[2] = {nullptr, nullptr};
+    static constexpr size_t kFloats = 2u << 20;  // 8 MB each
+};
+Staging g_staging;
+
+// Copies the points of all views -- `fpp` floats per point, view i's at src.ptrs[i] or, for one flat array, at
+// src.flat + fpp * off[i] -- into device memory at dst, view after view.  The host side gathers chunk k + 1 into pinned
+// memory on several threads while chunk k crosses the bus.
+int upload_views(ccalib_solver* s, float* dst, const HostViews& src, int fpp, const std::vector<int>& off) {
+    const int nviews = (int)off.size() - 1;
+    const size_t total = (size_t)fpp * off[nviews];
+    std::lock_guard<std::mutex> lock(g_staging.mu);
+    for (int b = 0; b < 2; b++)
+        if (!g_staging.buf[b]) HIP_TRY(hipHostMalloc(&g_staging.buf[b], sizeof(float) * Staging::kFloats, hipHostMallocDefault));
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    struct EvGuard {
+        hipEvent_t* e;
+        ~EvGuard() {
+            for (int b = 0; b < 2; b++)
+                if (e[b]) (void)hipEventDestroy(e[b]);
+        }
+    } guard{ev};
+    for (int b = 0; b < 2; b++) HIP_TRY(hipEventCreateWithFlags(&ev[b], hipEventDisableTiming));
+    const int nthreads = std::max(1, std::min(16, omp_get_max_threads()));
+    int v0 = 0;
+    size_t f0 = 0;  // floats already sent (flat source: position in the flat array)
+    for (int k = 0; f0 < total; k++) {
+        const int b = k & 1;
+        if (k >= 2) HIP_TRY(hipEventSynchronize(ev[b]));
+        float* stage = g_staging.buf[b];
+        size_t n = 0;
+        if (src.flat) {
+            n = std::min(Staging::kFloats, total - f0);
+            const size_t piece = (n + nthreads - 1) / nthreads;
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+            for (int t = 0; t < nthreads; t++) {
+                const size_t a = (size_t)t * piece, e = std::min(n, a + piece);
+                if (a < e) std::memcpy(stage + a, src.flat + f0 + a, sizeof(float) * (e - a));
+            }
+        } else {
+            int v1 = v0;
+            while (v1 < nviews && (size_t)fpp * (off[v1 + 1] - off[v0]) <= Staging::kFloats) v1++;
+            if (v1 == v0) return set_error(CCALIB_ERR_ARG, "view %d has more points than one upload chunk holds", v0);
+            n = (size_t)fpp * (off[v1] - off[v0]);
+            const int base = off[v0];
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+            for (int v = v0; v < v1; v++)
+                std::memcpy(stage + (size_t)fpp * (off[v] - base), src.ptrs[v], sizeof(float) * fpp * (off[v + 1] - off[v]));
+            v0 = v1;
+        }
+        HIP_TRY(hipMemcpyAsync(dst + f0, stage, sizeof(float) * n, hipMemcpyHostToDevice, s->stream));
+        HIP_TRY(hipEventRecord(ev[b], s->stream));
+        f0 += n;
+    }
+    // the staging buffers go back to the pool only when the copies out of them are done
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return CCALIB_OK;
+}
+
+}  // namespace
+
+int solver_create_views(ccalib_solver** out, int device, int ncams, int nviews, const int* npts, HostViews obj, int shared_board,
+                        HostViews img1, HostViews img2) {
+    if (!out || !npts || (!obj.flat && !obj.ptrs) || (!img1.flat && !img1.ptrs) || nviews < 1 || (ncams != 1 && ncams != 2) ||
+        (ncams == 2 && !img2.flat && !img2.ptrs))
         return set_error(CCALIB_ERR_ARG, "ccalib_solver_create: bad arguments");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
@@ -1194,11 +1390,11 @@ int ccalib_solver_create(ccalib_solver** out, int device, int ncams, int nviews,
     }
     s->total = off[nviews];
     // a shared board too large for LDS is replicated per view instead
-    std::vector<float> expanded;
+    const float* board = obj.flat ? obj.flat : obj.ptrs[0];
+    std::vector<const float*> same_board;
     if (shared_board && npts[0] > 1024) {
-        expanded.resize((size_t)3 * s->total);
-        for (int i = 0; i < nviews; i++) std::memcpy(&expanded[(size_t)3 * off[i]], obj_xyz, sizeof(float) * 3 * npts[0]);
-        obj_xyz = expanded.data();
+        same_board.assign(nviews, board);
+        obj = HostViews{nullptr, same_board.data()};
         shared_board = 0;
         s->shared_board = false;
     }
@@ -1230,73 +1426,185 @@ int ccalib_solver_create(ccalib_solver** out, int device, int ncams, int nviews,
     if (fused_geom(s->maxnp, s->shared_board, s->board_np).lds_bytes > 64 * 1024) s->use_fused = false;
     s->nblk64 = (nviews + 63) / 64;
     s->npad = (nviews + 63) / 64 * 64;
-    HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-    size_t nobj = shared_board ? (size_t)3 * s->board_np : (size_t)3 * s->total;
-    HIP_TRY(hipMalloc(&s->d_obj, sizeof(float) * nobj));
-    HIP_TRY(hipMalloc(&s->d_off, sizeof(int) * (nviews + 1)));
-    HIP_TRY(hipMemcpy(s->d_obj, obj_xyz, sizeof(float) * nobj, hipMemcpyHostToDevice));
+    if (void* st = g_pool.take(device, BlockPool::kStream, 0, nullptr))
+        s->stream = (hipStream_t)st;
+    else
+        HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    const size_t nobj = shared_board ? (size_t)3 * s->board_np : (size_t)3 * s->total;
+    const size_t N = nviews;
+    // one allocation, carved: first pass adds the sizes up, second hands the pieces out
+    auto layout = [&](Carver& c) {
+        s->d_obj = c.take<float>(nobj);
+        s->d_off = c.take<int>(N + 1);
+        for (int cam = 0; cam < ncams; cam++) s->d_img[cam] = c.take<float2>(s->total);
+        s->d_pose_prev = c.take<double>(6 * N);
+        s->d_pose_cur = c.take<double>(6 * N);
+        s->d_pose_retry = c.take<double>(6 * N);
+        s->d_pc = c.take<double>(kPoseConstStride * N);
+        s->d_pc_retry = c.take<double>(kPoseConstStride * N);
+        if (ncams == 2) {
+            s->d_pose3 = c.take<double>(6 * N);
+            s->d_pc3 = c.take<double>(kPoseConstStride * N);
+            for (int b = 0; b < 2; b++) s->d_cmp[b] = c.take<double>((size_t)kCmpRows * s->npad);
+            s->d_pose_init1 = c.take<double>(6 * N);
+            s->d_sums_tab = c.take<short>(4 * (quad_nlr(12) + quad_ngram(12)));
+            s->d_view_tab = c.take<short>(stereo_view_table(12, nullptr));
+        }
+        for (int q = 0; q < 2; q++) s->d_red[q] = c.take<double>(ccalib_solver::kRedCap);
+        s->d_ctrl = c.take<LmCtrl>(2);
+        s->d_maps = c.take<LmMaps>(1);
+        s->d_counter = c.take<unsigned>(64);
+        // initialisation (ccalib_solver_init_*)
+        s->d_status = c.take<int>(N);
+        s->d_parked_view = c.take<int>(N + 1);
+        s->d_parked_state = c.take<double>((size_t)kParkedDoubles * N);
+        s->d_init_part = c.take<double>(5 * (N + 1));
+    };
+    Carver sizing{nullptr};
+    layout(sizing);
+    int rc = pool_device_alloc(device, sizing.used, &s->arena, &s->arena_bytes);
+    if (rc) return rc;
+    Carver carve{s->arena};
+    layout(carve);
     HIP_TRY(hipMemcpy(s->d_off, off.data(), sizeof(int) * (nviews + 1), hipMemcpyHostToDevice));
-    const float* imgs[2] = {img1_uv, img2_uv};
-    for (int c = 0; c < ncams; c++) {
-        HIP_TRY(hipMalloc(&s->d_img[c], sizeof(float2) * s->total));
-        HIP_TRY(hipMemcpy(s->d_img[c], imgs[c], sizeof(float2) * s->total, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemsetAsync(s->d_pose_prev, 0, sizeof(double) * 6 * nviews, s->stream));
+    HIP_TRY(hipMemsetAsync(s->d_ctrl, 0, sizeof(LmCtrl) * 2, s->stream));
+    HIP_TRY(hipMemsetAsync(s->d_counter, 0, sizeof(unsigned) * 64, s->stream));
+    if (shared_board)
+        HIP_TRY(hipMemcpy(s->d_obj, board, sizeof(float) * nobj, hipMemcpyHostToDevice));
+    else if ((rc = upload_views(s, s->d_obj, obj, 3, off)))
+        return rc;
+    const HostViews imgs[2] = {img1, img2};
+    for (int c = 0; c < ncams; c++)
+        if ((rc = upload_views(s, reinterpret_cast<float*>(s->d_img[c]), imgs[c], 2, off))) return rc;
+    {   // both slots' sums and flags in one pinned block; coherent (uncached on the device side): the host reads
+        // these while the stream that writes them is still running
+        const size_t per = sizeof(double) * ccalib_solver::kRedCap + 256;
+        s->pinned = static_cast<char*>(g_pool.take(device, BlockPool::kPinned, 2 * per, nullptr));
+        if (!s->pinned) HIP_TRY(hipHostMalloc(&s->pinned, 2 * per, hipHostMallocCoherent));
+        s->pinned_bytes = 2 * per;
+        for (int q = 0; q < 2; q++) {
+            s->h_red[q] = reinterpret_cast<double*>(s->pinned + q * per);
+            s->h_flag[q] = reinterpret_cast<unsigned long long*>(s->pinned + q * per + sizeof(double) * ccalib_solver::kRedCap);
+            *s->h_flag[q] = 0;
+        }
     }
-    HIP_TRY(hipMalloc(&s->d_pose_prev, sizeof(double) * 6 * nviews));
-    HIP_TRY(hipMalloc(&s->d_pose_cur, sizeof(double) * 6 * nviews));
-    HIP_TRY(hipMalloc(&s->d_pose_retry, sizeof(double) * 6 * nviews));
-    HIP_TRY(hipMemset(s->d_pose_prev, 0, sizeof(double) * 6 * nviews));
-    HIP_TRY(hipMalloc(&s->d_pc, sizeof(double) * kPoseConstStride * nviews));
-    HIP_TRY(hipMalloc(&s->d_pc_retry, sizeof(double) * kPoseConstStride * nviews));
-    if (ncams == 2) {
-        HIP_TRY(hipMalloc(&s->d_pose3, sizeof(double) * 6 * nviews));
-        HIP_TRY(hipMalloc(&s->d_pc3, sizeof(double) * kPoseConstStride * nviews));
-        for (int b = 0; b < 2; b++) HIP_TRY(hipMalloc(&s->d_cmp[b], sizeof(double) * kCmpRows * s->npad));
-    }
-    for (int q = 0; q < 2; q++) {
-        HIP_TRY(hipMalloc(&s->d_red[q], sizeof(double) * ccalib_solver::kRedCap));
-        // coherent (uncached on the device side): the host reads these while the stream that writes them is still running
-        HIP_TRY(hipHostMalloc(&s->h_red[q], sizeof(double) * ccalib_solver::kRedCap, hipHostMallocCoherent));
-        HIP_TRY(hipHostMalloc(&s->h_flag[q], sizeof(unsigned long long), hipHostMallocCoherent));
-        *s->h_flag[q] = 0;
-    }
-    HIP_TRY(hipMalloc(&s->d_ctrl, sizeof(LmCtrl) * 2));
-    HIP_TRY(hipMemset(s->d_ctrl, 0, sizeof(LmCtrl) * 2));
-    HIP_TRY(hipMalloc(&s->d_maps, sizeof(LmMaps)));
     std::memset(&s->h_maps, 0, sizeof(LmMaps));
     if (const char* e = std::getenv("CCALIB_CHAIN")) s->chain_enabled = std::atoi(e) != 0;
     if (const char* e = std::getenv("CCALIB_NO_RETRY_AHEAD")) s->retry_enabled = std::atoi(e) == 0;
     if (const char* e = std::getenv("CCALIB_DUAL_BACKSUB")) s->dual_backsub = std::atoi(e) != 0;
     if (const char* e = std::getenv("CCALIB_SPLIT_PUBLISH")) s->split_publish = std::atoi(e) != 0;
-    HIP_TRY(hipMalloc(&s->d_counter, sizeof(unsigned)));
-    HIP_TRY(hipMemset(s->d_counter, 0, sizeof(unsigned)));
     s->segs.nseg = 0;
+    HIP_TRY(hipStreamSynchronize(s->stream));
     guard.s = nullptr;
     *out = s;
     return CCALIB_OK;
 }
+
+// The stream has been drained: the solver's blocks go to the pool (or back to the driver when the pool is full).
+void solver_release_blocks(ccalib_solver* s) {
+    g_pool.give(s->device, BlockPool::kDevice, s->arena, s->arena_bytes);
+    g_pool.give(s->device, BlockPool::kDevice, s->arena2, s->arena2_bytes);
+    g_pool.give(s->device, BlockPool::kPinned, s->pinned, s->pinned_bytes);
+    g_pool.give(s->device, BlockPool::kStream, s->stream, 0);
+    s->arena = s->arena2 = s->pinned = nullptr;
+    s->stream = nullptr;
+}
+
+int solver_arena2(ccalib_solver* s, size_t bytes) {
+    if (bytes <= s->arena2_bytes) return CCALIB_OK;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    g_pool.give(s->device, BlockPool::kDevice, s->arena2, s->arena2_bytes);
+    s->arena2 = nullptr, s->arena2_bytes = 0;
+    return pool_device_alloc(s->device, bytes, &s->arena2, &s->arena2_bytes);
+}
+
+// Device -> host through the pinned staging buffers: the copy engine fills one while host threads empty the other
+// into the caller's (pageable) memory.
+int download(ccalib_solver* s, void* dst, const void* src, size_t bytes) {
+    if (bytes < (1u << 20)) {
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        return CCALIB_OK;
+    }
+    std::lock_guard<std::mutex> lock(g_staging.mu);
+    for (int b = 0; b < 2; b++)
+        if (!g_staging.buf[b]) HIP_TRY(hipHostMalloc(&g_staging.buf[b], sizeof(float) * Staging::kFloats, hipHostMallocDefault));
+    const size_t chunk = std::min<size_t>(sizeof(float) * Staging::kFloats, 2u << 20);  // small pieces: the unpacking overlaps
+    const int nthreads = std::max(1, std::min(8, omp_get_max_threads()));
+    const size_t nchunks = (bytes + chunk - 1) / chunk;
+    const size_t per_buf = sizeof(float) * Staging::kFloats / chunk;  // pieces one staging buffer holds
+    // all pieces are queued at once into the two buffers' slots (2 * per_buf pieces in flight at most)
+    size_t done = 0;
+    while (done < nchunks) {
+        const size_t batch = std::min(nchunks - done, 2 * per_buf);
+        for (size_t k = 0; k < batch; k++) {
+            const size_t off = (done + k) * chunk, n = std::min(chunk, bytes - off);
+            char* stage = reinterpret_cast<char*>(g_staging.buf[k / per_buf]) + (k % per_buf) * chunk;
+            HIP_TRY(hipMemcpyAsync(stage, static_cast<const char*>(src) + off, n, hipMemcpyDeviceToHost, s->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        const size_t off0 = done * chunk, nb = std::min(batch * chunk, bytes - off0);
+        // the batch lies in the two buffers piece after piece; copy it out on several threads
+        const size_t piece = (nb + nthreads - 1) / nthreads;
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+        for (int t = 0; t < nthreads; t++) {
+            size_t a = (size_t)t * piece, e = std::min(nb, a + piece);
+            while (a < e) {
+                const size_t k = a / chunk, in = a % chunk, n = std::min(e - a, chunk - in);
+                const char* stage = reinterpret_cast<const char*>(g_staging.buf[k / per_buf]) + (k % per_buf) * chunk + in;
+                std::memcpy(static_cast<char*>(dst) + off0 + a, stage, n);
+                a += n;
+            }
+        }
+        done += batch;
+    }
+    return CCALIB_OK;
+}
+
+// The refined poses as cv::calibrateCamera returns them: rvecs and tvecs apart, nviews x 3 each.  The r|t records
+// come through the pinned staging buffers and are taken apart on several host threads on the way out.
+int solver_get_poses_split(ccalib_solver* s, double* rvecs, double* tvecs) {
+    if (!s || !s->started || !rvecs || !tvecs) return set_error(CCALIB_ERR_STATE, "poses requested before set_start");
+    HIP_TRY(hipSetDevice(s->device));
+    std::lock_guard<std::mutex> lock(g_staging.mu);
+    for (int b = 0; b < 2; b++)
+        if (!g_staging.buf[b]) HIP_TRY(hipHostMalloc(&g_staging.buf[b], sizeof(float) * Staging::kFloats, hipHostMallocDefault));
+    const size_t per_buf = sizeof(float) * Staging::kFloats / (6 * sizeof(double));  // views one buffer holds
+    [[maybe_unused]] const int nthreads = std::max(1, std::min(8, omp_get_max_threads()));
+    for (size_t v0 = 0; v0 < (size_t)s->nviews; v0 += 2 * per_buf) {
+        const size_t nv = std::min<size_t>(2 * per_buf, s->nviews - v0);
+        for (int b = 0; b < 2; b++) {
+            const size_t a = std::min(nv, b * per_buf), e = std::min(nv, (b + 1) * per_buf);
+            if (a < e)
+                HIP_TRY(hipMemcpyAsync(g_staging.buf[b], s->d_pose_cur + 6 * (v0 + a), sizeof(double) * 6 * (e - a),
+                                       hipMemcpyDeviceToHost, s->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(s->stream));
+#pragma omp parallel for num_threads(nthreads) schedule(static) if (nv > 4096)
+        for (long long i = 0; i < (long long)nv; i++) {
+            const double* rec = reinterpret_cast<const double*>(g_staging.buf[(size_t)i / per_buf]) + 6 * ((size_t)i % per_buf);
+            double* r = rvecs + 3 * (v0 + i);
+            double* t = tvecs + 3 * (v0 + i);
+            r[0] = rec[0], r[1] = rec[1], r[2] = rec[2], t[0] = rec[3], t[1] = rec[4], t[2] = rec[5];
+        }
+    }
+    return CCALIB_OK;
+}
+
+}  // namespace ccalib
+
+extern "C" {
+
+size_t ccalib_release_cached_memory(void) { return ccalib::g_pool.trim(); }
 
 void ccalib_solver_destroy(ccalib_solver* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->comm) ncclCommDestroy(s->comm);
-    (void)hipFree(s->d_obj), (void)hipFree(s->d_off), (void)hipFree(s->d_img[0]), (void)hipFree(s->d_img[1]);
-    (void)hipFree(s->d_pose_prev), (void)hipFree(s->d_pose_cur), (void)hipFree(s->d_pose3);
-    (void)hipFree(s->d_sums_tab);
-    (void)hipFree(s->d_pose_retry);
-    (void)hipFree(s->d_pc_retry);
-    (void)hipFree(s->d_view_tab);
-    for (int b = 0; b < 2; b++) (void)hipFree(s->d_cmp[b]), (void)hipFree(s->d_blk[0][b]), (void)hipFree(s->d_blk[1][b]);
-    (void)hipFree(s->d_pc), (void)hipFree(s->d_pc3), (void)hipFree(s->d_ctrl), (void)hipFree(s->d_maps);
-    for (int q = 0; q < 2; q++) {
-        (void)hipFree(s->d_part[q]), (void)hipFree(s->d_red[q]);
-        if (s->h_red[q]) (void)hipHostFree(s->h_red[q]);
-        if (s->h_flag[q]) (void)hipHostFree(s->h_flag[q]);
-    }
-    (void)hipFree(s->d_status), (void)hipFree(s->d_pose_init1), (void)hipFree(s->d_parked_view), (void)hipFree(s->d_parked_state);
-    (void)hipFree(s->d_counter);
+    ccalib::solver_release_blocks(s);
     for (hipEvent_t e : s->prof_ev) (void)hipEventDestroy(e);
-    if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
 
@@ -1328,12 +1636,6 @@ int ccalib_solver_set_start(ccalib_solver* s, const double* intr, const unsigned
     if (!m) return set_error(CCALIB_ERR_UNSUPPORTED, "no kernel column set covers mask 0x%x", need);
     for (int c = 0; c < s->ncams; c++) {
         s->rational[c] = rat;
-        for (int b = 0; b < 2; b++)
-            if (m != s->ops[c] || !s->d_blk[c][b]) {
-                if (s->d_blk[c][b]) (void)hipFree(s->d_blk[c][b]);
-                s->d_blk[c][b] = nullptr;  // a failed allocation below must not leave a freed pointer behind
-                HIP_TRY(hipMalloc(&s->d_blk[c][b], sizeof(double) * (size_t)m->NBLK * s->npad));
-            }
         s->ops[c] = m;
     }
     if (s->ncams == 2) {
@@ -1341,12 +1643,10 @@ int ccalib_solver_set_start(ccalib_solver* s, const double* intr, const unsigned
         if (!n) return set_error(CCALIB_ERR_UNSUPPORTED, "stereo column count %d is not built in", m->NC);
         std::vector<short> tab(n);
         stereo_sums_table(m->NC, tab.data());
-        if (!s->d_sums_tab) HIP_TRY(hipMalloc(&s->d_sums_tab, sizeof(short) * 4 * (quad_nlr(12) + quad_ngram(12))));
         HIP_TRY(hipMemcpy(s->d_sums_tab, tab.data(), sizeof(short) * n, hipMemcpyHostToDevice));
         {
             std::vector<short> vt(stereo_view_table(m->NC, nullptr));
             if (!stereo_view_table(m->NC, vt.data())) return set_error(CCALIB_ERR_STATE, "stereo sum table is inconsistent");
-            if (!s->d_view_tab) HIP_TRY(hipMalloc(&s->d_view_tab, sizeof(short) * stereo_view_table(12, nullptr)));
             HIP_TRY(hipMemcpy(s->d_view_tab, vt.data(), sizeof(short) * vt.size(), hipMemcpyHostToDevice));
         }
         // Few views: four lanes per view fill the chip where one lane per view would leave most of it idle.
@@ -1355,17 +1655,24 @@ int ccalib_solver_set_start(ccalib_solver* s, const double* intr, const unsigned
         s->sums_quad = e ? std::atoi(e) != 0 : s->nblk64 < 512;
         s->sums_rows = s->sums_quad ? stereo_sums_rows(s->nviews) : s->nblk64;
     }
-    {
-        size_t need = part_capacity(s);
-        if (need > s->part_cap) {
-            for (int q = 0; q < 2; q++) {
-                if (s->d_part[q]) (void)hipFree(s->d_part[q]);
-                s->d_part[q] = nullptr;
-            }
-            s->part_cap = 0;
-            for (int q = 0; q < 2; q++) HIP_TRY(hipMalloc(&s->d_part[q], sizeof(double) * need));
-            s->part_cap = need;
+    {   // what depends on the column set: the per-view blocks (two buffers per camera) and the partial-result arenas
+        const size_t need_part = part_capacity(s);
+        auto layout2 = [&](Carver& c) {
+            for (int cam = 0; cam < s->ncams; cam++)
+                for (int b = 0; b < 2; b++) s->d_blk[cam][b] = c.take<double>((size_t)m->NBLK * s->npad);
+            for (int q = 0; q < 2; q++) s->d_part[q] = c.take<double>(need_part);
+        };
+        Carver sizing{nullptr};
+        layout2(sizing);
+        if (sizing.used > s->arena2_bytes) {
+            for (int cam = 0; cam < 2; cam++) s->d_blk[cam][0] = s->d_blk[cam][1] = nullptr;
+            s->d_part[0] = s->d_part[1] = nullptr;
+            int rc2 = ccalib::solver_arena2(s, sizing.used);
+            if (rc2) return rc2;
         }
+        Carver carve{s->arena2};
+        layout2(carve);
+        s->part_cap = need_part;
         s->part_used = 0;
         s->segs.nseg = 0;
     }
@@ -1434,14 +1741,12 @@ int ccalib_solver_init_intrinsics(ccalib_solver* s, int cam, int width, int heig
     A[2] = !width ? 0.5 : (width - 1) * 0.5;
     A[5] = !height ? 0.5 : (height - 1) * 0.5;
     const int grid = (s->nviews + a.VPB - 1) / a.VPB;
-    double* d_part = nullptr;
-    HIP_TRY(hipMalloc(&d_part, sizeof(double) * 5 * grid));
+    if (grid > s->nviews + 1) return set_error(CCALIB_ERR_STATE, "init_intrinsics: more workgroups than views");
+    double* d_part = s->d_init_part;
     launch_init_intrinsics(a, A[2], A[5], d_part, s->stream);
     std::vector<double> part((size_t)5 * grid);
-    hipError_t e = hipMemcpyAsync(part.data(), d_part, sizeof(double) * part.size(), hipMemcpyDeviceToHost, s->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
-    (void)hipFree(d_part);
-    HIP_TRY(e);
+    HIP_TRY(hipMemcpyAsync(part.data(), d_part, sizeof(double) * part.size(), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
     double sums[5] = {0, 0, 0, 0, 0};
     for (int b = 0; b < grid; b++)
         for (int k = 0; k < 5; k++) sums[k] += part[(size_t)5 * b + k];
@@ -1475,16 +1780,7 @@ int ccalib_solver_init_poses(ccalib_solver* s, int cam, const double* K, const d
     InitArgs a = init_args(s, cam);
     if (!init_geometry(a, true))
         return set_error(CCALIB_ERR_UNSUPPORTED, "a view with %d points does not fit the initialisation kernels' LDS staging", s->maxnp);
-    if (!s->d_status) HIP_TRY(hipMalloc(&s->d_status, sizeof(int) * s->nviews));
-    double* dst = s->d_pose_cur;
-    if (cam == 1) {
-        if (!s->d_pose_init1) HIP_TRY(hipMalloc(&s->d_pose_init1, sizeof(double) * 6 * s->nviews));
-        dst = s->d_pose_init1;
-    }
-    if (!s->d_parked_view) {
-        HIP_TRY(hipMalloc(&s->d_parked_view, sizeof(int) * ((size_t)s->nviews + 1)));
-        HIP_TRY(hipMalloc(&s->d_parked_state, sizeof(double) * kParkedDoubles * (size_t)s->nviews));
-    }
+    double* dst = cam == 1 ? s->d_pose_init1 : s->d_pose_cur;
     Parked parked{s->d_parked_view + s->nviews, s->d_parked_view, s->d_parked_state};
     (void)hipGetLastError();  // an error another HIP user of this thread left behind is not ours to report
     launch_init_pose(a, cp, rational, dst, s->d_status, parked, s->stream);
@@ -1689,8 +1985,8 @@ int ccalib_solver_get(ccalib_solver* s, double* intr, double* rt, double* lr, do
     if (intr)
         for (int c = 0; c < s->ncams; c++) std::memcpy(intr + 18 * c, s->intr[c], sizeof(double) * 18);
     if (rt) {
-        HIP_TRY(hipStreamSynchronize(s->stream));
-        HIP_TRY(hipMemcpy(rt, s->d_pose_cur, sizeof(double) * 6 * s->nviews, hipMemcpyDeviceToHost));
+        int rc = ccalib::download(s, rt, s->d_pose_cur, sizeof(double) * 6 * s->nviews);
+        if (rc) return rc;
     }
     if (lr) std::memcpy(lr, s->lr, sizeof(double) * 6);
     if (err) *err = s->last_err;

@@ -126,6 +126,37 @@ int ccalib_stereo_calibrate(int nviews, const int* npts, const float* obj_xyz, c
                             double* rms, ccalib_stats* stats);
 
 /*
+ * The same two calls over one pointer per view instead of one flat array: obj_views[i] -> npts[i] x 3 floats,
+ * img_views[i] -> npts[i] x 2 floats.  This is the memory a std::vector<std::vector<cv::Point3f>> /
+ * std::vector<std::vector<cv::Point2f>> already holds (monocular_chessboard.cpp:249, :295-305: every view's
+ * object points are a copy of one board; binocular_chessboard.cpp:118-131), so a binding passes &views[i][0]
+ * and nothing is gathered on the host: the library copies each view straight into its pinned upload buffer.
+ * Entries of obj_views may all point at the same board.  Every other argument, the results and the error
+ * behaviour are those of the flat calls.
+ */
+int ccalib_calibrate_camera_views(int nviews, const int* npts, const float* const* obj_views,
+                                  const float* const* img_views, int width, int height, double* K, double* dist,
+                                  int ndist, double* rvecs, double* tvecs, int flags, int term_type, int max_iter,
+                                  double eps, const double* init_rt, double* rms, ccalib_stats* stats);
+int ccalib_stereo_calibrate_views(int nviews, const int* npts, const float* const* obj_views,
+                                  const float* const* img1_views, const float* const* img2_views, double* K1,
+                                  double* dist1, double* K2, double* dist2, int width, int height, double* R,
+                                  double* T, double* E, double* F, int flags, int term_type, int max_iter, double eps,
+                                  const double* init_rt, const double* init_lr, double* rt_out, double* rms,
+                                  ccalib_stats* stats);
+
+/*
+ * Memory kept between calls.  No counterpart in the reference: OpenCV's calls own nothing on a device.  Every
+ * whole-call entry point builds a device-resident problem and tears it down again; the device blocks, the pinned
+ * block and the stream of a destroyed problem are kept (per device, up to CCALIB_POOL_MB megabytes of device memory
+ * in total, default 1024; CCALIB_POOL_MB=0 keeps nothing) and handed to the next one that they fit, which saves the
+ * allocation and release calls (about a millisecond per call).  Two pinned 8 MB upload buffers are created on first
+ * use and kept as well.  This call returns all cached blocks to the driver; the result is the number of device
+ * bytes released.  A request that the driver cannot satisfy releases the cache by itself and tries again.
+ */
+size_t ccalib_release_cached_memory(void);
+
+/*
  * cv::projectPoints over many views + the RMS the reference recomputes from it
  * (monocular_circle.cpp:5-29).  proj_uv (optional) receives sum(npts) x 2 floats,
  * per_view_rms (optional) nviews doubles, total_rms the global figure.

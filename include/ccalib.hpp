@@ -66,6 +66,29 @@ inline void flatten(const std::vector<std::vector<Point3f>>& obj, const std::vec
         for (const Point2f& p : img[i]) { m.push_back(p.x); m.push_back(p.y); }
     }
 }
+// One pointer per view into the vectors the caller already holds (Point3f / Point2f are plain float triples / pairs):
+// what the ccalib_*_views entry points take, so that nothing is gathered here.
+struct ViewPointers {
+    std::vector<int> npts;
+    std::vector<const float*> obj, img[2];
+};
+inline ViewPointers view_pointers(const std::vector<std::vector<Point3f>>& obj, const std::vector<std::vector<Point2f>>& img1,
+                                  const std::vector<std::vector<Point2f>>* img2 = nullptr) {
+    static_assert(sizeof(Point3f) == 3 * sizeof(float) && sizeof(Point2f) == 2 * sizeof(float), "points must be packed floats");
+    if (obj.size() != img1.size() || (img2 && img2->size() != obj.size()) || obj.empty())
+        throw Exception(CCALIB_ERR_ARG, "objectPoints / imagePoints view counts differ");
+    ViewPointers vp;
+    for (size_t i = 0; i < obj.size(); i++) {
+        if (obj[i].size() != img1[i].size() || (img2 && (*img2)[i].size() != obj[i].size()))
+            throw Exception(CCALIB_ERR_ARG, "objectPoints / imagePoints sizes differ");
+        if (obj[i].empty()) throw Exception(CCALIB_ERR_ARG, "a view without points");
+        vp.npts.push_back((int)obj[i].size());
+        vp.obj.push_back(&obj[i][0].x);
+        vp.img[0].push_back(&img1[i][0].x);
+        if (img2) vp.img[1].push_back(&(*img2)[i][0].x);
+    }
+    return vp;
+}
 // OpenCV's prepareCameraMatrix: empty -> eye(3).  (Output length of the distortion vector: ccalib_dist_coeffs_out.)
 inline Mat camera_or_eye(const Mat& K) { return K.total() == 9 ? K : Mat::eye(3); }
 }  // namespace detail
@@ -75,9 +98,8 @@ inline double calibrateCameraRO(const std::vector<std::vector<Point3f>>& objectP
                                 Mat& cameraMatrix, Mat& distCoeffs, std::vector<Mat>& rvecs, std::vector<Mat>& tvecs,
                                 std::vector<Point3f>& newObjPoints, int flags = 0, TermCriteria criteria = TermCriteria()) {
     if (iFixedPoint >= 0) throw Exception(CCALIB_ERR_UNSUPPORTED, "object-releasing calibration (iFixedPoint >= 0) is not built");
-    std::vector<int> npts;
-    std::vector<float> o, m;
-    detail::flatten(objectPoints, imagePoints, npts, o, m);
+    detail::ViewPointers vp = detail::view_pointers(objectPoints, imagePoints);
+    const std::vector<int>& npts = vp.npts;
     Mat K = detail::camera_or_eye(cameraMatrix);
     int nd = ccalib_dist_coeffs_out(flags, 0);
     std::vector<double> d(nd, 0.);
@@ -85,9 +107,9 @@ inline double calibrateCameraRO(const std::vector<std::vector<Point3f>>& objectP
     int n = (int)npts.size();
     std::vector<double> rv((size_t)3 * n), tv((size_t)3 * n);
     double rms = 0;
-    detail::check(ccalib_calibrate_camera(n, npts.data(), o.data(), m.data(), imageSize.width, imageSize.height, K.v.data(),
-                                          d.data(), nd, rv.data(), tv.data(), flags, criteria.type, criteria.maxCount,
-                                          criteria.epsilon, nullptr, &rms, nullptr));
+    detail::check(ccalib_calibrate_camera_views(n, npts.data(), vp.obj.data(), vp.img[0].data(), imageSize.width, imageSize.height,
+                                                K.v.data(), d.data(), nd, rv.data(), tv.data(), flags, criteria.type,
+                                                criteria.maxCount, criteria.epsilon, nullptr, &rms, nullptr));
     cameraMatrix = K;
     // prepareDistCoeffs keeps the caller's orientation: a column for an n x 1 input, a row otherwise (empty included)
     distCoeffs = distCoeffs.cols == 1 ? Mat(nd, 1) : Mat(1, nd);
@@ -126,20 +148,18 @@ inline double stereoCalibrate(const std::vector<std::vector<Point3f>>& objectPoi
                               Mat& cameraMatrix2, Mat& distCoeffs2, Size imageSize, Mat& R, Mat& T, Mat& E, Mat& F,
                               int flags = CALIB_FIX_INTRINSIC,
                               TermCriteria criteria = TermCriteria(TermCriteria::COUNT + TermCriteria::EPS, 30, 1e-6)) {
-    std::vector<int> npts, npts2;
-    std::vector<float> o, m1, o2, m2;
-    detail::flatten(objectPoints, imagePoints1, npts, o, m1);
-    detail::flatten(objectPoints, imagePoints2, npts2, o2, m2);
+    detail::ViewPointers vp = detail::view_pointers(objectPoints, imagePoints1, &imagePoints2);
     Mat K1 = detail::camera_or_eye(cameraMatrix1), K2 = detail::camera_or_eye(cameraMatrix2);
     std::vector<double> d1(14, 0.), d2(14, 0.);
     for (size_t i = 0; i < distCoeffs1.total() && i < 14; i++) d1[i] = distCoeffs1.v[i];
     for (size_t i = 0; i < distCoeffs2.total() && i < 14; i++) d2[i] = distCoeffs2.v[i];
     R = Mat(3, 3), T = Mat(3, 1), E = Mat(3, 3), F = Mat(3, 3);
     double rms = 0;
-    detail::check(ccalib_stereo_calibrate((int)npts.size(), npts.data(), o.data(), m1.data(), m2.data(), K1.v.data(),
-                                          d1.data(), K2.v.data(), d2.data(), imageSize.width, imageSize.height, R.v.data(),
-                                          T.v.data(), E.v.data(), F.v.data(), flags, criteria.type, criteria.maxCount,
-                                          criteria.epsilon, nullptr, nullptr, nullptr, &rms, nullptr));
+    detail::check(ccalib_stereo_calibrate_views((int)vp.npts.size(), vp.npts.data(), vp.obj.data(), vp.img[0].data(),
+                                                vp.img[1].data(), K1.v.data(), d1.data(), K2.v.data(), d2.data(), imageSize.width,
+                                                imageSize.height, R.v.data(), T.v.data(), E.v.data(), F.v.data(), flags,
+                                                criteria.type, criteria.maxCount, criteria.epsilon, nullptr, nullptr, nullptr, &rms,
+                                                nullptr));
     cameraMatrix1 = K1, cameraMatrix2 = K2;
     int nd = ccalib_dist_coeffs_out(flags, 1);
     distCoeffs1 = distCoeffs1.cols == 1 ? Mat(nd, 1) : Mat(1, nd);
