@@ -163,8 +163,7 @@ __device__ __forceinline__ void for_points(const PassArgs& a, const Lane<G>& l, 
 // keeps the FP64 pipe issuing is the number of wavefronts per SIMD: with nothing staged in LDS but the shared
 // board, eight fit (the G-lane layout below, with its per-wavefront stage, allows two).
 template <bool RAT>
-__global__ __launch_bounds__(kBlock) void k_err_wave(PassArgs a, CamParams cp, const double* __restrict__ pc,
-                                                     double* part) {
+__device__ __forceinline__ void err_wave_body(const PassArgs& a, const CamParams& cp, const double* __restrict__ pc, double* part) {
     using M = Model<0u, false, RAT>;
     __shared__ double red[kWaves];
     stage_board(a);
@@ -254,6 +253,21 @@ __global__ __launch_bounds__(kBlock) void k_err_wave(PassArgs a, CamParams cp, c
         }
     }
     block_reduce_store<1>(acc, red, part + blockIdx.x);
+}
+
+template <bool RAT>
+__global__ __launch_bounds__(kBlock) void k_err_wave(PassArgs a, CamParams cp, const double* __restrict__ pc, double* part) {
+    err_wave_body<RAT>(a, cp, pc, part);
+}
+
+// Both cameras of a stereo rig in one launch (blockIdx.y = camera): at ten thousand pairs a residual pass is a few
+// microseconds of work, and a second launch costs as much again in the gap between the two.
+template <bool RAT>
+__global__ __launch_bounds__(kBlock) void k_err_wave_pair(ErrPair e) {
+    if (blockIdx.y == 0)
+        err_wave_body<RAT>(e.a[0], e.cp[0], e.pc[0], e.part[0]);
+    else
+        err_wave_body<RAT>(e.a[1], e.cp[1], e.pc[1], e.part[1]);
 }
 
 // ---- projectPoints + per-view squared error (the reference's RMS re-check, monocular_circle.cpp:5-29) ----
@@ -1036,6 +1050,14 @@ void launch_err_wave(const PassArgs& a, const CamParams& cp, bool rational, cons
         k_err_wave<true><<<dim3(grid), dim3(kBlock), lds, st>>>(a, cp, pc, part);
     else
         k_err_wave<false><<<dim3(grid), dim3(kBlock), lds, st>>>(a, cp, pc, part);
+}
+
+void launch_err_wave_pair(const ErrPair& e, bool rational, int grid, hipStream_t st) {
+    const unsigned lds = (unsigned)(sizeof(float) * (e.a[0].shared_board ? 3 * (size_t)e.a[0].board_np : 0));
+    if (rational)
+        k_err_wave_pair<true><<<dim3(grid, 2), dim3(kBlock), lds, st>>>(e);
+    else
+        k_err_wave_pair<false><<<dim3(grid, 2), dim3(kBlock), lds, st>>>(e);
 }
 
 void launch_reproj(const PassArgs& a, const CamParams& cp, bool rational, int grid, float2* proj, double* view_err,

@@ -103,6 +103,14 @@ const ModelOps* find_model(unsigned need_mask, bool aspect, bool need_rational);
 // sum of squared residuals from pose records (pc: nviews x kPoseConstStride), one wavefront per view
 void launch_err_wave(const PassArgs&, const CamParams&, bool rational, const double* pc, int grid, double* part,
                      hipStream_t);
+// The same for both cameras of a stereo rig in one launch (same board layout, same distortion model).
+struct ErrPair {
+    PassArgs a[2];
+    CamParams cp[2];
+    const double* pc[2];
+    double* part[2];
+};
+void launch_err_wave_pair(const ErrPair& e, bool rational, int grid, hipStream_t st);
 // projected pixels (as float, optional) and the squared reprojection error of every view; a non-null `bad`
 // points at a device word which, when non-zero, makes the kernel return at once
 void launch_reproj(const PassArgs&, const CamParams&, bool rational, int grid, float2* proj, double* view_err,

@@ -184,6 +184,8 @@ struct ccalib_solver {
     } retry;
     bool retry_enabled = true;            // CCALIB_NO_RETRY_AHEAD=1 turns it off
     bool dual_backsub = false;            // CCALIB_DUAL_BACKSUB=1: the retry's back-substitution rides in the first trial's kernel
+    bool fold_compose = true;             // stereo: a trial followed by a run-ahead Jacobian pass composes camera 1's poses,
+                                          // derivatives included, in its own kernel (CCALIB_FOLD_COMPOSE=0: separate launch)
     double* d_pose_retry = nullptr;       // trial poses of such a retry (they must not touch the first trial's)
     double* d_pc_retry = nullptr;         // ... and their records
     std::vector<double> com_U, com_gs;    // shared block and gradient of the committed Jacobian, as the driver holds them
@@ -426,12 +428,16 @@ int stereo_compose(ccalib_solver* s, bool with_jac, int buf, const double* pose1
 
 // Launches the Schur-sum kernels of buffer `buf` for `lambda` and appends their column sums to the reduction
 // at `ofs`.  Layout appended: upper triangle (kc(kc+1)/2) then right-hand side (kc), kc = kernel columns.
-int enqueue_schur(ccalib_solver* s, int buf, double lambda, int ofs, const LmCtrl* ctrl, int lr_ofs = -1) {
+//   lambda2 != 0: the same sums for a second damping, appended at ofs2 (stereo: same launch, other half of the grid).
+int enqueue_schur(ccalib_solver* s, int buf, double lambda, int ofs, const LmCtrl* ctrl, int lr_ofs = -1, double lambda2 = 0.,
+                  int ofs2 = -1) {
     int kc = s->kcols(), nsum = kc * (kc + 1) / 2 + kc;
     if (s->ncams == 1) {
         PART_TAKE(part, s, (size_t)s->nblk64 * nsum);
         s->ops[0]->schur(s->d_blk[0][buf], s->npad, s->nviews, lambda, part, s->stream, ctrl);
-        return queue_colsum(s, part, s->nblk64, nsum, ofs);
+        int rc = queue_colsum(s, part, s->nblk64, nsum, ofs);
+        if (rc || lambda2 == 0.) return rc;
+        return enqueue_schur(s, buf, lambda2, ofs2, ctrl);
     }
     // stereo: one kernel takes the Schur sums and, with lr_ofs >= 0, the sums that enter the shared block through
     // the relative pose: B^T V3 B (21), B^T ge3 (6), W3 B (NC1 x 6)
@@ -442,13 +448,18 @@ int enqueue_schur(ccalib_solver* s, int buf, double lambda, int ofs, const LmCtr
         PART_TAKE(pl, s, (size_t)s->sums_rows * nlr);
         part_lr = pl;
     }
+    double* part2 = nullptr;
+    if (lambda2 != 0.) {
+        PART_TAKE(p2, s, (size_t)s->sums_rows * nsum);
+        part2 = p2;
+    }
     bool ok;
     if (s->sums_quad)
         ok = launch_stereo_sums(s->ops[0]->NC, s->d_blk[0][buf], s->d_blk[1][buf], s->d_cmp[buf], s->lr_jac[buf], s->npad,
-                                s->nviews, lambda, s->d_sums_tab, s->sums_rows, part, part_lr, s->stream);
+                                s->nviews, lambda, s->d_sums_tab, s->sums_rows, part, part_lr, s->stream, lambda2, part2);
     else {
         ok = launch_stereo_view_sums(s->ops[0]->NC, s->d_blk[0][buf], s->d_blk[1][buf], s->d_cmp[buf], s->lr_jac[buf], s->npad,
-                                     s->nviews, lambda, s->d_view_tab, part, s->stream);
+                                     s->nviews, lambda, s->d_view_tab, part, s->stream, lambda2, part2);
         if (ok && part_lr)
             ok = launch_stereo_lr_sums(s->ops[1]->NC, s->d_blk[1][buf], s->d_cmp[buf], s->lr_jac[buf], s->npad, s->nviews,
                                        part_lr, s->stream);
@@ -456,6 +467,7 @@ int enqueue_schur(ccalib_solver* s, int buf, double lambda, int ofs, const LmCtr
     if (!ok) return set_error(CCALIB_ERR_UNSUPPORTED, "stereo column count %d is not built in", s->ops[0]->NC);
     int rc = queue_colsum(s, part, s->sums_rows, nsum, ofs);
     if (!rc && part_lr) rc = queue_colsum(s, part_lr, s->sums_rows, nlr, lr_ofs);
+    if (!rc && part2) rc = queue_colsum(s, part2, s->sums_rows, nsum, ofs2);
     return rc;
 }
 
@@ -501,9 +513,10 @@ bool tile12_possible(const ccalib_solver* s) {
 // poses `pose` (records in d_pc must match them).  By-value parameters (the solver's current intrinsics and
 // relative pose) are used unless `ctrl` names the control block of a run-ahead iteration.
 // lambda_extra != 0: a second set of Schur sums, for that damping, follows the first at offset jac_layout().end.
+// composed: camera 1's poses, their records and the composition derivatives in d_cmp[buf] are already in place.
 int enqueue_jac(ccalib_solver* s, int buf, double lambda_hint, int ofs, const double* pose, const LmCtrl* ctrl,
-                double lambda_extra = 0.) {
-    int rc = stereo_compose(s, true, buf, pose);
+                double lambda_extra = 0., bool composed = false) {
+    int rc = composed ? CCALIB_OK : stereo_compose(s, true, buf, pose);
     if (rc) return rc;
     s->n_jac_exec++;
     const JacLayout L = jac_layout(s);
@@ -550,8 +563,9 @@ int enqueue_jac(ccalib_solver* s, int buf, double lambda_hint, int ofs, const do
             m->jac_view(a, cp, s->grid_view, s->d_blk[c][buf], s->npad, s->stream);
         }
     }
-    if ((rc = enqueue_schur(s, buf, lambda_hint, ofs + L.schur_ofs, ctrl, s->ncams == 2 ? ofs + L.lr_ofs : -1))) return rc;
-    if (lambda_extra != 0. && (rc = enqueue_schur(s, buf, lambda_extra, ofs + L.end, ctrl))) return rc;
+    if ((rc = enqueue_schur(s, buf, lambda_hint, ofs + L.schur_ofs, ctrl, s->ncams == 2 ? ofs + L.lr_ofs : -1, lambda_extra,
+                            ofs + L.end)))
+        return rc;
     if (ofs + L.end + (lambda_extra != 0. ? L.nsum : 0) > kPredOfs) return set_error(CCALIB_ERR_STATE, "reduction buffer too small");
     return CCALIB_OK;
 }
@@ -833,8 +847,7 @@ int be_reduce(void* user, double lambda, const int* fidx, int nf, double* Ssum, 
         // the same round trip: one more pass over the blocks against a whole host turn-around if they are needed.
         const int lv = lambda_level(lambda);
         const double lambda_up = s->speculate && lv < 32 ? std::exp((lv + 1 - 16) * std::log(10.)) : 0.;
-        int rc = enqueue_schur(s, s->cur, lambda, 0, nullptr);
-        if (!rc && lambda_up != 0.) rc = enqueue_schur(s, s->cur, lambda_up, nsum, nullptr);
+        int rc = enqueue_schur(s, s->cur, lambda, 0, nullptr, -1, lambda_up, nsum);
         if (rc) return rc;
         const double* red;
         if ((rc = finish_reduction(s, lambda_up != 0. ? 2 * nsum : nsum, &red))) return rc;
@@ -914,7 +927,10 @@ int launch_trial(ccalib_solver* s, double lambda, double lambda_next, const int*
         const bool want_pc = s->ops[0]->jac_fused && s->use_fused;
         // a residual pass follows unless the next Jacobian pass is run ahead (which composes with derivatives):
         // camera 1's trial poses then come out of this kernel too
+        // ... and when it is run ahead, the composition derivatives that pass needs come out of it as well
         const bool compose_here = !ahead;
+        const bool compose_jac = ahead && !second && s->fold_compose;
+        const bool want_pc3 = compose_here || (s->ops[1]->jac_fused && s->use_fused);
         StereoLR lr_new;
         for (int i = 0; i < 6; i++) lr_new.v[i] = shared_new[i];
         StereoSecondTrial st2;
@@ -930,12 +946,13 @@ int launch_trial(ccalib_solver* s, double lambda, double lambda_next, const int*
         }
         if (!launch_stereo_backsub(s->ops[0]->NC, s->d_blk[0][cur], s->d_blk[1][cur], s->d_cmp[cur], s->lr_jac[cur],
                                    s->npad, s->nviews, lambda, sd, s->d_pose_prev, s->d_pose_cur, npart,
-                                   want_pc ? s->d_pc : nullptr, lr_new, compose_here ? s->d_pose3 : nullptr,
-                                   compose_here ? s->d_pc3 : nullptr, s->stream, second ? &st2 : nullptr))
+                                   want_pc ? s->d_pc : nullptr, lr_new, compose_here || compose_jac ? s->d_pose3 : nullptr,
+                                   (compose_here || compose_jac) && want_pc3 ? s->d_pc3 : nullptr, s->stream,
+                                   second ? &st2 : nullptr, compose_jac ? s->d_cmp[cur ^ 1] : nullptr))
             return set_error(CCALIB_ERR_UNSUPPORTED, "stereo column count %d is not built in", s->ops[0]->NC);
         s->pc_fresh = want_pc;
-        s->pc3_fresh = compose_here;
-        stereo_composed = compose_here;
+        s->pc3_fresh = (compose_here || compose_jac) && want_pc3;
+        stereo_composed = compose_here || compose_jac;
     }
     s->t_think += std::chrono::duration<double>(tl0 - s->t_wait_end).count();
     s->t_launch1 += std::chrono::duration<double>(std::chrono::steady_clock::now() - tl0).count();
@@ -946,7 +963,7 @@ int launch_trial(ccalib_solver* s, double lambda, double lambda_next, const int*
     t->lam2 = 0.;
     if (ahead) {
         t->lam2 = retry_lambda(s, lambda_next);
-        if ((rc = enqueue_jac(s, cur ^ 1, lambda_next, 2, s->d_pose_cur, nullptr, t->lam2))) return rc;
+        if ((rc = enqueue_jac(s, cur ^ 1, lambda_next, 2, s->d_pose_cur, nullptr, t->lam2, stereo_composed))) return rc;
         const JacLayout L0 = jac_layout(s);
         t->n = 2 + L0.end + (t->lam2 != 0. ? L0.nsum : 0);
         if (chain_possible(s)) {
@@ -961,12 +978,28 @@ int launch_trial(ccalib_solver* s, double lambda, double lambda_next, const int*
         // residual pass at the trial point
         s->n_err_exec++;
         if (!stereo_composed && (rc = stereo_compose(s, false, cur, s->d_pose_cur))) return rc;
-        for (int c = 0; c < s->ncams; c++) {
-            CamParams cp = cam_params(s->intr[c], s->aspect[c]);
-            PART_TAKE(epart, s, (size_t)s->grid_err);
-            enqueue_err(s, c, cp, epart);
-            if ((rc = queue_colsum(s, epart, s->grid_err, 1, 2 + c))) return rc;
-        }
+        if (s->ncams == 2 && s->rational[0] == s->rational[1]) {
+            ErrPair e;
+            for (int c = 0; c < 2; c++) {
+                e.a[c] = pass_args(s, c, c == 0 ? s->d_pose_cur : s->d_pose3);
+                e.cp[c] = cam_params(s->intr[c], s->aspect[c]);
+                double* pc = c == 0 ? s->d_pc : s->d_pc3;
+                bool& fresh = c == 0 ? s->pc_fresh : s->pc3_fresh;
+                if (!fresh) launch_pose_const(e.a[c].pose, s->nviews, pc, s->stream);
+                fresh = true;
+                e.pc[c] = pc;
+                PART_TAKE(epart, s, (size_t)s->grid_err);
+                e.part[c] = epart;
+                if ((rc = queue_colsum(s, epart, s->grid_err, 1, 2 + c))) return rc;
+            }
+            launch_err_wave_pair(e, s->rational[0], s->grid_err, s->stream);
+        } else
+            for (int c = 0; c < s->ncams; c++) {
+                CamParams cp = cam_params(s->intr[c], s->aspect[c]);
+                PART_TAKE(epart, s, (size_t)s->grid_err);
+                enqueue_err(s, c, cp, epart);
+                if ((rc = queue_colsum(s, epart, s->grid_err, 1, 2 + c))) return rc;
+            }
         t->n = 2 + s->ncams;
         if ((rc = submit_reduction(s, t->n, nullptr, nullptr, &t->p))) return rc;
     }
@@ -1493,6 +1526,7 @@ int solver_create_views(ccalib_solver** out, int device, int ncams, int nviews, 
     if (const char* e = std::getenv("CCALIB_CHAIN")) s->chain_enabled = std::atoi(e) != 0;
     if (const char* e = std::getenv("CCALIB_NO_RETRY_AHEAD")) s->retry_enabled = std::atoi(e) == 0;
     if (const char* e = std::getenv("CCALIB_DUAL_BACKSUB")) s->dual_backsub = std::atoi(e) != 0;
+    if (const char* e = std::getenv("CCALIB_FOLD_COMPOSE")) s->fold_compose = std::atoi(e) != 0;
     if (const char* e = std::getenv("CCALIB_SPLIT_PUBLISH")) s->split_publish = std::atoi(e) != 0;
     s->segs.nseg = 0;
     HIP_TRY(hipStreamSynchronize(s->stream));

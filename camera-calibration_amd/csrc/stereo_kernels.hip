@@ -82,16 +82,14 @@ __device__ __forceinline__ void mul33(const double A[9], const double B[9], doub
         for (int j = 0; j < 3; j++) C[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
 }
 
-__global__ __launch_bounds__(64) void k_compose(const double* pose1, StereoLR lr, int nviews, int npad, double* pose3,
-                                                double* cmp, double* pc3) {
-    int v = blockIdx.x * 64 + threadIdx.x;
-    if (v >= nviews) return;
-    const double* p = pose1 + 6 * (size_t)v;
-    double r1[3] = {p[0], p[1], p[2]}, t1[3] = {p[3], p[4], p[5]};
+// Camera 1's pose for view v: (r3, t3) = (r2, t2) o (r1, t1) into p3; with JAC the derivatives of the composition
+// (dr3/dr1, dr3/dr2, dt3/dr2; 27 numbers, one column of `cmp` per number) are stored for that view as well.
+template <bool JAC>
+__device__ __forceinline__ void compose_view(const double r1[3], const double t1[3], const StereoLR& lr, double p3[6], double* cmp,
+                                             int npad, int v) {
     double r2[3] = {lr.v[0], lr.v[1], lr.v[2]};
     double R1[9], R2[9], dR1[3][9], dR2[3][9], R3[9];
-    bool jac = cmp != nullptr;
-    if (jac) {
+    if (JAC) {
         rodrigues<true>(r1, R1, dR1);
         rodrigues<true>(r2, R2, dR2);
     } else {
@@ -100,17 +98,10 @@ __global__ __launch_bounds__(64) void k_compose(const double* pose1, StereoLR lr
     }
     mul33(R2, R1, R3);
     M2V m = rodrigues_m2v(R3);
-    double* q = pose3 + 6 * (size_t)v;
-    q[0] = m.r[0], q[1] = m.r[1], q[2] = m.r[2];
+    p3[0] = m.r[0], p3[1] = m.r[1], p3[2] = m.r[2];
 #pragma unroll
-    for (int i = 0; i < 3; i++) q[3 + i] = R2[i * 3] * t1[0] + R2[i * 3 + 1] * t1[1] + R2[i * 3 + 2] * t1[2] + lr.v[3 + i];
-    if (pc3) {  // camera 1's pose in the form the fused Jacobian kernel reads
-        double p3[6] = {q[0], q[1], q[2], q[3], q[4], q[5]}, rec[16];
-        store_pose_const(p3, rec);
-#pragma unroll
-        for (int k = 0; k < 16; k++) pc3[16 * (size_t)v + k] = rec[k];
-    }
-    if (!jac) return;
+    for (int i = 0; i < 3; i++) p3[3 + i] = R2[i * 3] * t1[0] + R2[i * 3 + 1] * t1[1] + R2[i * 3 + 2] * t1[2] + lr.v[3 + i];
+    if (!JAC || !cmp) return;
 #pragma unroll
     for (int j = 0; j < 3; j++) {
         double D[9], col[3];
@@ -126,6 +117,27 @@ __global__ __launch_bounds__(64) void k_compose(const double* pose1, StereoLR lr
         for (int i = 0; i < 3; i++)  // dt3/dr2_j = dR2_j t1
             cmp[(size_t)(18 + i * 3 + j) * npad + v] =
                 dR2[j][i * 3] * t1[0] + dR2[j][i * 3 + 1] * t1[1] + dR2[j][i * 3 + 2] * t1[2];
+    }
+}
+
+__global__ __launch_bounds__(64) void k_compose(const double* pose1, StereoLR lr, int nviews, int npad, double* pose3,
+                                                double* cmp, double* pc3) {
+    int v = blockIdx.x * 64 + threadIdx.x;
+    if (v >= nviews) return;
+    const double* p = pose1 + 6 * (size_t)v;
+    double r1[3] = {p[0], p[1], p[2]}, t1[3] = {p[3], p[4], p[5]}, p3[6];
+    if (cmp)
+        compose_view<true>(r1, t1, lr, p3, cmp, npad, v);
+    else
+        compose_view<false>(r1, t1, lr, p3, nullptr, npad, v);
+    double* q = pose3 + 6 * (size_t)v;
+#pragma unroll
+    for (int k = 0; k < 6; k++) q[k] = p3[k];
+    if (pc3) {  // camera 1's pose in the form the fused Jacobian kernel reads
+        double rec[16];
+        store_pose_const(p3, rec);
+#pragma unroll
+        for (int k = 0; k < 16; k++) pc3[16 * (size_t)v + k] = rec[k];
     }
 }
 
@@ -294,8 +306,15 @@ constexpr int kStageRow = 68;  // doubles between products in the LDS stage: qua
 template <int NC, bool WITH_LR>
 __global__ __launch_bounds__(64) void k_stereo_sums(const double* __restrict__ blk0, const double* __restrict__ blk1,
                                                     const double* __restrict__ cmp, StereoLR lr, int npad, int nviews,
-                                                    int ngroups, double lambda, const short* __restrict__ tab,
-                                                    double* __restrict__ part, double* __restrict__ part_lr) {
+                                                    int ngroups, double lambda_y0, const short* __restrict__ tab,
+                                                    double* __restrict__ part_y0, double* __restrict__ part_lr, double lambda_y1,
+                                                    double* __restrict__ part_y1) {
+    // gridDim.y = 2: the same sums for a second damping, side by side with the first (the relative-pose sums do
+    // not depend on the damping: the second half pushes zeros in their place and stores none of them)
+    const bool second = blockIdx.y != 0;
+    const double lambda = second ? lambda_y1 : lambda_y0;
+    double* __restrict__ part = second ? part_y1 : part_y0;
+    const bool with_lr = WITH_LR && !second;
     constexpr int NB = 27 + 6 * NC, SC = quad_sc(NC), NS = quad_nslot(NC), KC = 6 + 2 * NC;
     constexpr int LRV = quad_nlr(NC), P0 = WITH_LR ? LRV : 0, P = P0 + quad_ngram(NC), NCH = (P + kQuadChunk - 1) / kQuadChunk;
     constexpr int NSUM = KC * (KC + 1) / 2 + KC, NOUT = 27 + 6 * NC;
@@ -379,7 +398,11 @@ __global__ __launch_bounds__(64) void k_stereo_sums(const double* __restrict__ b
             if constexpr (WITH_LR && LS >= 0) {
                 double Brr[9], Btr[9];
 #pragma unroll
-                for (int k = 0; k < 9; k++) Brr[k] = cmp[(size_t)(9 + k) * npad + vv], Btr[k] = cmp[(size_t)(18 + k) * npad + vv];
+                for (int k = 0; k < 9; k++) Brr[k] = Btr[k] = 0.;
+                if (with_lr) {
+#pragma unroll
+                    for (int k = 0; k < 9; k++) Brr[k] = cmp[(size_t)(9 + k) * npad + vv], Btr[k] = cmp[(size_t)(18 + k) * npad + vv];
+                }
                 static_for<0, 6>([&](auto jj) {
                     constexpr int j = decltype(jj)::value;
                     double o = j < 3 ? x[0] * Brr[j] + x[1] * Brr[3 + j] + x[2] * Brr[6 + j] + x[3] * Btr[j] + x[4] * Btr[3 + j] + x[5] * Btr[6 + j]
@@ -483,7 +506,7 @@ __global__ __launch_bounds__(64) void k_stereo_sums(const double* __restrict__ b
             const int e = t[4 * p + a];
             if (e >= 0)
                 part[(size_t)blockIdx.x * NSUM + e] = acc[ch];
-            else if (e <= -2)
+            else if (e <= -2 && with_lr)
                 part_lr[(size_t)blockIdx.x * NOUT + (-2 - e)] = acc[ch];
         }
     }
@@ -528,8 +551,11 @@ struct TabReducer {  // LaneReducer with all 64 lanes adding and a destination t
 template <int NC>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_stereo_view_sums(
     const double* __restrict__ blk0, const double* __restrict__ blk1, const double* __restrict__ cmp, StereoLR lr, int npad,
-    int nviews, double lambda, const short* __restrict__ dst, double* __restrict__ part) {
+    int nviews, double lambda_y0, const short* __restrict__ dst, double* __restrict__ part_y0, double lambda_y1,
+    double* __restrict__ part_y1) {
     constexpr int NB = 27 + 6 * NC, KC = 6 + 2 * NC, NSUM = KC * (KC + 1) / 2 + KC;
+    const double lambda = blockIdx.y ? lambda_y1 : lambda_y0;  // gridDim.y = 2: a second damping side by side
+    double* __restrict__ part = blockIdx.y ? part_y1 : part_y0;
     const int v = blockIdx.x * 64 + threadIdx.x;
     const bool live = v < nviews;
     const int vv = live ? v : nviews - 1;
@@ -682,12 +708,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // DUAL: a second trial step from the same blocks in the same pass -- damping lambda2, step d2 -- whose poses go to
 // pose_cur2 (records to pc2, norms to part2).  The blocks are what the kernel waits for (1 224 bytes per pair at six
 // columns); the second factorisation and solve ride along for a few hundred instructions.
-template <int NC0, int NC1, bool DUAL>
+// CMPJ: the trial point is where the next Jacobian pass is taken (run ahead of the accept decision): camera 1's pose comes
+// with the composition derivatives, into cmp_next -- what a k_compose launch in front of that pass would do.
+template <int NC0, int NC1, bool DUAL, bool CMPJ>
 __global__ __launch_bounds__(64) void k_stereo_backsub(const double* blk0, const double* blk1, const double* cmp,
                                                        StereoLR lr, int npad, int nviews, double lambda, StereoDelta d,
                                                        const double* pose_prev, double* pose_cur, double* part, double* pc,
                                                        StereoLR lr_new, double* pose3, double* pc3, double lambda2,
-                                                       StereoDelta d2, double* pose_cur2, double* part2, double* pc2) {
+                                                       StereoDelta d2, double* pose_cur2, double* part2, double* pc2,
+                                                       double* cmp_next) {
     int v = blockIdx.x * 64 + threadIdx.x;
     bool live = v < nviews;
     int vv = live ? v : nviews - 1;
@@ -771,18 +800,9 @@ __global__ __launch_bounds__(64) void k_stereo_backsub(const double* blk0, const
     };
     if constexpr (DUAL) trial(lambda2, rhs2, pose_cur2, pc2, part2);
     trial(lambda, rhs, pose_cur, pc, part);   // last: pnew is this trial's pose below
-    if (pose3) {  // camera 1's trial pose (k_compose without the derivatives): (r3,t3) = lr_new o (r1,t1)
-        double r1[3] = {pnew[0], pnew[1], pnew[2]}, r2[3] = {lr_new.v[0], lr_new.v[1], lr_new.v[2]};
-        double R1[9], R2n[9], R3[9], p3[6];
-        rodrigues<false>(r1, R1, nullptr);
-        rodrigues<false>(r2, R2n, nullptr);
-        mul33(R2n, R1, R3);
-        M2V m = rodrigues_m2v(R3);
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-            p3[i] = m.r[i];
-            p3[3 + i] = R2n[i * 3] * pnew[3] + R2n[i * 3 + 1] * pnew[4] + R2n[i * 3 + 2] * pnew[5] + lr_new.v[3 + i];
-        }
+    if (pose3) {  // camera 1's trial pose: (r3,t3) = lr_new o (r1,t1)
+        double p3[6];
+        compose_view<CMPJ>(pnew, pnew + 3, lr_new, p3, live ? cmp_next : nullptr, npad, vv);
         wave_store_rows<6>(p3, sm, pose3 + 6 * (size_t)v0, nlive);
         if (pc3) {
             double rec[16];
@@ -840,13 +860,17 @@ template <int NC>
 static void backsub_t(dim3 grid, hipStream_t st, const double* blk0, const double* blk1, const double* cmp,
                       const StereoLR& lr, int npad, int nviews, double lambda, const StereoDelta& d,
                       const double* pose_prev, double* pose_cur, double* part, double* pc, const StereoLR& lr_new, double* pose3,
-                      double* pc3, const StereoSecondTrial* t2) {
+                      double* pc3, const StereoSecondTrial* t2, double* cmp_next) {
     if (t2)
-        hipLaunchKernelGGL((k_stereo_backsub<NC, NC, true>), grid, dim3(64), 0, st, blk0, blk1, cmp, lr, npad, nviews, lambda, d,
-                           pose_prev, pose_cur, part, pc, lr_new, pose3, pc3, t2->lambda, t2->d, t2->pose, t2->part, t2->pc);
+        hipLaunchKernelGGL((k_stereo_backsub<NC, NC, true, false>), grid, dim3(64), 0, st, blk0, blk1, cmp, lr, npad, nviews, lambda,
+                           d, pose_prev, pose_cur, part, pc, lr_new, pose3, pc3, t2->lambda, t2->d, t2->pose, t2->part, t2->pc,
+                           nullptr);
+    else if (cmp_next)
+        hipLaunchKernelGGL((k_stereo_backsub<NC, NC, false, true>), grid, dim3(64), 0, st, blk0, blk1, cmp, lr, npad, nviews, lambda,
+                           d, pose_prev, pose_cur, part, pc, lr_new, pose3, pc3, 0., d, nullptr, nullptr, nullptr, cmp_next);
     else
-        hipLaunchKernelGGL((k_stereo_backsub<NC, NC, false>), grid, dim3(64), 0, st, blk0, blk1, cmp, lr, npad, nviews, lambda, d,
-                           pose_prev, pose_cur, part, pc, lr_new, pose3, pc3, 0., d, nullptr, nullptr, nullptr);
+        hipLaunchKernelGGL((k_stereo_backsub<NC, NC, false, false>), grid, dim3(64), 0, st, blk0, blk1, cmp, lr, npad, nviews,
+                           lambda, d, pose_prev, pose_cur, part, pc, lr_new, pose3, pc3, 0., d, nullptr, nullptr, nullptr, nullptr);
 }
 
 // column counts of the built-in column sets (kernels.hip)
@@ -963,43 +987,48 @@ int stereo_view_table(int nc, short* out) {
 
 template <int NC>
 static void view_sums_t(dim3 grid, hipStream_t st, const double* blk0, const double* blk1, const double* cmp, const StereoLR& lr,
-                        int npad, int nviews, double lambda, const short* dst, double* part) {
-    hipLaunchKernelGGL((k_stereo_view_sums<NC>), grid, dim3(64), 0, st, blk0, blk1, cmp, lr, npad, nviews, lambda, dst, part);
+                        int npad, int nviews, double lambda, const short* dst, double* part, double lambda2, double* part2) {
+    hipLaunchKernelGGL((k_stereo_view_sums<NC>), grid, dim3(64), 0, st, blk0, blk1, cmp, lr, npad, nviews, lambda, dst, part, lambda2,
+                       part2);
 }
 
 bool launch_stereo_view_sums(int nc, const double* blk0, const double* blk1, const double* cmp, const StereoLR& lr, int npad,
-                             int nviews, double lambda, const short* dst, double* part, hipStream_t st) {
-    dim3 grid((nviews + 63) / 64);
-    CCALIB_FOR_NC(nc, view_sums_t, grid, st, blk0, blk1, cmp, lr, npad, nviews, lambda, dst, part);
+                             int nviews, double lambda, const short* dst, double* part, hipStream_t st, double lambda2,
+                             double* part2) {
+    dim3 grid((nviews + 63) / 64, part2 ? 2 : 1);
+    CCALIB_FOR_NC(nc, view_sums_t, grid, st, blk0, blk1, cmp, lr, npad, nviews, lambda, dst, part, lambda2, part2);
     return true;
 }
 
 template <int NC>
 static void sums_t(dim3 grid, hipStream_t st, const double* blk0, const double* blk1, const double* cmp, const StereoLR& lr,
-                   int npad, int nviews, int ngroups, double lambda, const short* tab, double* part, double* part_lr) {
+                   int npad, int nviews, int ngroups, double lambda, const short* tab, double* part, double* part_lr, double lambda2,
+                   double* part2) {
     if (part_lr)
         hipLaunchKernelGGL((k_stereo_sums<NC, true>), grid, dim3(64), 0, st, blk0, blk1, cmp, lr, npad, nviews, ngroups, lambda,
-                           tab, part, part_lr);
+                           tab, part, part_lr, lambda2, part2);
     else
         hipLaunchKernelGGL((k_stereo_sums<NC, false>), grid, dim3(64), 0, st, blk0, blk1, cmp, lr, npad, nviews, ngroups, lambda,
-                           tab, part, part_lr);
+                           tab, part, part_lr, lambda2, part2);
 }
 
 bool launch_stereo_sums(int nc, const double* blk0, const double* blk1, const double* cmp, const StereoLR& lr, int npad,
-                        int nviews, double lambda, const short* tab, int rows, double* part, double* part_lr, hipStream_t st) {
-    dim3 grid(rows);
+                        int nviews, double lambda, const short* tab, int rows, double* part, double* part_lr, hipStream_t st,
+                        double lambda2, double* part2) {
+    dim3 grid(rows, part2 ? 2 : 1);
     const int ngroups = (nviews + 15) / 16;
-    CCALIB_FOR_NC(nc, sums_t, grid, st, blk0, blk1, cmp, lr, npad, nviews, ngroups, lambda, tab, part, part_lr);
+    CCALIB_FOR_NC(nc, sums_t, grid, st, blk0, blk1, cmp, lr, npad, nviews, ngroups, lambda, tab, part, part_lr, lambda2, part2);
     return true;
 }
 
 bool launch_stereo_backsub(int nc, const double* blk0, const double* blk1, const double* cmp, const StereoLR& lr,
                            int npad, int nviews, double lambda, const StereoDelta& d, const double* pose_prev,
                            double* pose_cur, double* part, double* pc, const StereoLR& lr_new, double* pose3, double* pc3,
-                           hipStream_t st, const StereoSecondTrial* second) {
+                           hipStream_t st, const StereoSecondTrial* second, double* cmp_next) {
+    if (cmp_next && (second || !pose3)) return false;  // the derivatives come with camera 1's pose, for one trial
     dim3 grid((nviews + 63) / 64);
     CCALIB_FOR_NC(nc, backsub_t, grid, st, blk0, blk1, cmp, lr, npad, nviews, lambda, d, pose_prev, pose_cur, part, pc, lr_new,
-                  pose3, pc3, second);
+                  pose3, pc3, second, cmp_next);
     return true;
 }
 

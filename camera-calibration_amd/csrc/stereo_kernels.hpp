@@ -56,13 +56,17 @@ bool launch_stereo_lr_sums(int nc, const double* blk1, const double* cmp, const 
 int stereo_sums_rows(int nviews);
 int stereo_sums_table(int nc, short* out);  // fills out (when not null), returns the entry count; 0: nc not built in
 bool launch_stereo_sums(int nc, const double* blk0, const double* blk1, const double* cmp, const StereoLR& lr, int npad,
-                        int nviews, double lambda, const short* tab, int rows, double* part, double* part_lr, hipStream_t st);
+                        int nviews, double lambda, const short* tab, int rows, double* part, double* part_lr, hipStream_t st,
+                        double lambda2 = 0., double* part2 = nullptr);
 // The Schur sums with one lane per view and one row of partial sums per 64 views: upper triangle of
 // sum W V'^-1 W^T and sum W V'^-1 ge over the columns [om_LR T_LR | camera 0 | camera 1]; `dst` = the device copy
 // of stereo_view_table(nc).
 int stereo_view_table(int nc, short* out);
 bool launch_stereo_view_sums(int nc, const double* blk0, const double* blk1, const double* cmp, const StereoLR& lr, int npad,
-                             int nviews, double lambda, const short* dst, double* part, hipStream_t st);
+                             int nviews, double lambda, const short* dst, double* part, hipStream_t st, double lambda2 = 0.,
+                             double* part2 = nullptr);
+// (both sums launchers: with part2 the same sums for a second damping, lambda2, go to part2 -- the grid's second half,
+// so that at small problems the two run side by side instead of one launch after the other)
 // A second trial step computed from the same read of the blocks (another damping, another step): its camera-0 poses,
 // their records (may be null) and its two step norms per 64 views go to buffers of its own.
 struct StereoSecondTrial {
@@ -77,7 +81,9 @@ bool launch_stereo_backsub(int nc, const double* blk0, const double* blk1, const
                            double* pose_cur, double* part, double* pc,  // pc: trial poses as records, or null
                            const StereoLR& lr_new, double* pose3, double* pc3,  // pose3 != null: camera 1's trial poses
                            hipStream_t st,                                        // for the relative pose lr_new as well
-                           const StereoSecondTrial* second = nullptr);
+                           const StereoSecondTrial* second = nullptr,
+                           double* cmp_next = nullptr);  // with pose3: the composition derivatives at the trial point too
+                                                         // (what launch_compose writes to `cmp`), for the Jacobian pass there
 
 // The assembled stereo view systems of a Jacobian pass, for inspection (tests): V nviews x 36, ge nviews x 6,
 // W nviews x (6 + 2 nc) x 6 in kernel column order [om_LR T_LR | camera 0 | camera 1], all device pointers.
