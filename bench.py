@@ -53,9 +53,11 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=20,
-                    help="untimed LM iterations from the same start (as many as --steps by default, so that every kernel and "
-                         "code path of the timed run has already run once)")
+    ap.add_argument("--warmup", type=int, default=600,
+                    help="untimed LM iterations, taken in runs of --steps iterations from the same start point, i.e. the very "
+                         "iterations the timed run executes.  The default keeps the GPU busy for about 0.15 s: the card takes "
+                         "about 0.1 s of load to reach its sustained clock (measured: 0.174 ms per step right after 20 "
+                         "warm-up steps, falling to 0.155 over the next ten runs)")
     ap.add_argument("--views", type=int, default=100_000, help="views per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-views", type=int, default=4000, help="views in the bounded CPU sample")
@@ -156,9 +158,9 @@ def main():
         return st, dt
 
     # warm-up: W untimed LM iterations from the start point
-    solver.set_start(intr, mask, rt0)
-    if args.warmup > 0:
-        solver.run(criteria=(3, args.warmup, 0.0))
+    for w0 in range(0, args.warmup, max(1, args.steps)):
+        solver.set_start(intr, mask, rt0)
+        solver.run(criteria=(3, min(args.steps, args.warmup - w0), 0.0))
     exec0 = solver.executed_passes()
     st, dt = timed_run()                     # THE timed region: value and ms_per_step come from this run alone
     exec1 = solver.executed_passes()
@@ -258,7 +260,7 @@ def main():
                       % (f"{args.views // 1000}k views/GPU" if args.scaling == "weak" else f"{args.views // 1000}k views in total"),
             "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "ms_per_step_min": min(spread), "ms_per_step_median": float(np.median(spread)),
-            "ms_per_step_max": max(spread), "ms_per_step_runs": len(spread),
+            "ms_per_step_max": max(spread), "ms_per_step_runs": len(spread), "ms_per_step_series": [round(x, 4) for x in spread],
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "configs[3]: monocular 9x6 chessboard, %d synthetic 640x480 views %s, "
@@ -299,9 +301,9 @@ def _stereo_start(pkg, synth, obj, st):
 
 def _timed_steps(s, start, steps, warmup, repeats=REPEATS):
     """K LM iterations from `start`, timed; then `repeats` more runs for the spread and one with in-loop events."""
-    s.set_start(**start)
-    if warmup > 0:
-        s.run(criteria=(3, warmup, 0.0))
+    for w0 in range(0, warmup, max(1, steps)):
+        s.set_start(**start)
+        s.run(criteria=(3, min(steps, warmup - w0), 0.0))
     ms, stt = [], None
     e0 = s.executed_passes()
     for r in range(1 + repeats):
@@ -459,8 +461,9 @@ def whole_call(pkg, obj, ms):
     pts = ms.img.shape[0] * ms.img.shape[1]
     return {"ms": round(dt * 1e3, 2), "lm_loop_ms": round(got["device_ms"], 2), "iters": got["iters"], "rms_px": got["rms"],
             "points_per_s": pts * got["jac_passes"] / dt,
-            "note": "host buffers in, results out: the Python wrapper's flattening of the point arrays (~5 ms here; a C or C++ "
-                    "caller hands over flat arrays), argument checks, upload, device initialisation, LM loop, download"}
+            "note": "host buffers in, results out (ccalib_calibrate_camera_views: one pointer per view, nothing gathered on "
+                    "the host): argument checks, upload through pinned staging, device initialisation, LM loop, download; "
+                    "device blocks come from the library's pool (the warm-up call above left them there)"}
 
 
 def opencv_check(pkg, synth):

@@ -52,6 +52,7 @@ using namespace ccalib;
 struct Pending {
     int slot = 0;
     unsigned long long seq = 0;
+    hipStream_t stream = nullptr;  // the stream the reduction was submitted to
 };
 
 struct ccalib_solver {
@@ -69,6 +70,14 @@ struct ccalib_solver {
     bool use_fused = true;
     unsigned lds_bytes = 0;
     hipStream_t stream = nullptr;
+    // A second stream for a trial step that is expected to be rejected while the retry prepared behind it is expected to be
+    // accepted: the retry and the Jacobian pass run ahead at its point go to `stream` first, the doomed trial's
+    // back-substitution, residual pass and reduction run beside them here (be_step_err).  It has camera-1 pose buffers
+    // and a completion counter of its own; everything else the two touch is distinct already.
+    hipStream_t aux = nullptr;
+    bool aux_enabled = true;  // chosen by problem size at creation; CCALIB_AUX_STREAM=0|1 decides otherwise
+    double *d_pose3_alt = nullptr, *d_pc3_alt = nullptr;
+    long long n_aside = 0;
     // Device memory comes from two allocations carved into pieces: `arena` (everything whose size the view table fixes:
     // points, poses, records, reduction buffers, initialisation state) and `arena2` (what depends on the column set:
     // the per-view blocks and the partial-result arenas); one pinned block holds both slots' host-visible sums and
@@ -323,7 +332,7 @@ int submit_reduction(ccalib_solver* s, int n, const LmCtrl* ctrl, LmStepArgs* st
     s->part_used = 0;
     s->slot ^= 1;
     HIP_TRY(hipGetLastError());
-    out->slot = q, out->seq = seq;
+    out->slot = q, out->seq = seq, out->stream = s->stream;
     return CCALIB_OK;
 }
 
@@ -334,7 +343,7 @@ int wait_reduction(ccalib_solver* s, const Pending& p, int n) {
     volatile unsigned long long* flag = s->h_flag[p.slot];
     for (unsigned spins = 0; *flag != p.seq; spins++) {
         if ((spins & 0xffff) == 0xffff) {  // a failed launch or a fault must not leave the host spinning
-            hipError_t q = hipStreamQuery(s->stream);
+            hipError_t q = hipStreamQuery(p.stream ? p.stream : s->stream);
             if (q != hipSuccess && q != hipErrorNotReady)
                 return set_error(CCALIB_ERR_HIP, "stream failed while waiting for a reduction: %s", hipGetErrorString(q));
             if (q == hipSuccess && *flag != p.seq) return set_error(CCALIB_ERR_HIP, "reduction finished without publishing");
@@ -1126,9 +1135,33 @@ int be_step_err(void* user, double lambda, double lambda_next, const int* fidx, 
             if (rc) return rc;
         }
         const bool dual = planned && s->ncams == 2 && s->dual_backsub;
-        if ((rc = launch_trial(s, lambda, lambda_next, fidx, nf, dshared, shared_new, s->steps_since_jac, &t, dual ? &plan : nullptr)))
-            return rc;
-        if (!t.ahead && planned && (rc = launch_retry_ahead(s, lambda, fidx, nf, plan, dual))) return rc;
+        const bool aside = planned && !dual && s->aux && !s->comm;
+        if (aside) {
+            // the retry and the pass behind it first, on the main stream: they are the longer chain, and what the next
+            // iteration waits for; the trial itself beside them (a sharded run keeps one stream: its all-reduces must
+            // stay in one order on every rank)
+            if ((rc = launch_retry_ahead(s, lambda, fidx, nf, plan, false))) return rc;
+            const bool pc3_main = s->pc3_fresh;  // the main camera-1 buffers hold the retry's composition
+            std::swap(s->stream, s->aux);
+            std::swap(s->d_pose3, s->d_pose3_alt);
+            std::swap(s->d_pc3, s->d_pc3_alt);
+            s->d_counter += 32;
+            s->pc3_fresh = false;
+            rc = launch_trial(s, lambda, lambda_next, fidx, nf, dshared, shared_new, s->steps_since_jac, &t, nullptr);
+            s->d_counter -= 32;
+            std::swap(s->d_pc3, s->d_pc3_alt);
+            std::swap(s->d_pose3, s->d_pose3_alt);
+            std::swap(s->stream, s->aux);
+            s->pc3_fresh = pc3_main;
+            if (rc) return rc;
+            if (t.ahead) return set_error(CCALIB_ERR_STATE, "a trial with a planned retry was given a Jacobian pass");
+            s->n_aside++;
+        } else {
+            if ((rc = launch_trial(s, lambda, lambda_next, fidx, nf, dshared, shared_new, s->steps_since_jac, &t,
+                                   dual ? &plan : nullptr)))
+                return rc;
+            if (!t.ahead && planned && (rc = launch_retry_ahead(s, lambda, fidx, nf, plan, dual))) return rc;
+        }
         if (s->retry.inflight) store_shared(s, shared_new);  // the solver's parameters are this trial's until the driver moves on
     }
     if ((rc = wait_reduction(s, t.p, t.n))) return rc;
@@ -1463,6 +1496,16 @@ int solver_create_views(ccalib_solver** out, int device, int ncams, int nviews, 
         s->stream = (hipStream_t)st;
     else
         HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    // Side by side pays while the passes leave the GPU room: 10 000 stereo pairs of 54 points go from 0.117 to 0.104 ms per
+    // iteration; at 100 000 pairs (0.463 against 0.466) and 100 000 mono views every CU is busy and nothing is gained.
+    s->aux_enabled = (long long)s->total * ncams <= 3000000;
+    if (const char* e = std::getenv("CCALIB_AUX_STREAM")) s->aux_enabled = std::atoi(e) != 0;
+    if (s->aux_enabled) {
+        if (void* st = g_pool.take(device, BlockPool::kStream, 0, nullptr))
+            s->aux = (hipStream_t)st;
+        else
+            HIP_TRY(hipStreamCreateWithFlags(&s->aux, hipStreamNonBlocking));
+    }
     const size_t nobj = shared_board ? (size_t)3 * s->board_np : (size_t)3 * s->total;
     const size_t N = nviews;
     // one allocation, carved: first pass adds the sizes up, second hands the pieces out
@@ -1478,6 +1521,8 @@ int solver_create_views(ccalib_solver** out, int device, int ncams, int nviews, 
         if (ncams == 2) {
             s->d_pose3 = c.take<double>(6 * N);
             s->d_pc3 = c.take<double>(kPoseConstStride * N);
+            s->d_pose3_alt = c.take<double>(6 * N);
+            s->d_pc3_alt = c.take<double>(kPoseConstStride * N);
             for (int b = 0; b < 2; b++) s->d_cmp[b] = c.take<double>((size_t)kCmpRows * s->npad);
             s->d_pose_init1 = c.take<double>(6 * N);
             s->d_sums_tab = c.take<short>(4 * (quad_nlr(12) + quad_ngram(12)));
@@ -1541,8 +1586,9 @@ void solver_release_blocks(ccalib_solver* s) {
     g_pool.give(s->device, BlockPool::kDevice, s->arena2, s->arena2_bytes);
     g_pool.give(s->device, BlockPool::kPinned, s->pinned, s->pinned_bytes);
     g_pool.give(s->device, BlockPool::kStream, s->stream, 0);
+    g_pool.give(s->device, BlockPool::kStream, s->aux, 0);
     s->arena = s->arena2 = s->pinned = nullptr;
-    s->stream = nullptr;
+    s->stream = s->aux = nullptr;
 }
 
 int solver_arena2(ccalib_solver* s, size_t bytes) {
@@ -1636,6 +1682,7 @@ void ccalib_solver_destroy(ccalib_solver* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->aux) (void)hipStreamSynchronize(s->aux);
     if (s->comm) ncclCommDestroy(s->comm);
     ccalib::solver_release_blocks(s);
     for (hipEvent_t e : s->prof_ev) (void)hipEventDestroy(e);
@@ -2050,6 +2097,8 @@ int ccalib_solver_describe(ccalib_solver* s, int out[8]) {
     out[3] = s->ops[0]->NC;
     out[4] = s->ncams;
     out[5] = s->sums_quad ? 1 : 0;
+    out[6] = s->aux ? 1 : 0;
+    out[7] = (int)std::min<long long>(s->n_aside, 0x7fffffff);
     return CCALIB_OK;
 }
 

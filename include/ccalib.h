@@ -339,7 +339,8 @@ int ccalib_solver_get(ccalib_solver* s, double* intr, double* rt, double* lr, do
  * How the solver runs its Jacobian pass (after set_start):  out[0] per-point kernel: 0 the two vector kernels, 1 the
  * fused matrix-pipe kernel on a 16-column tile (one launch per camera), 2 the fused kernel on a 12-column tile (every
  * camera in one launch);  out[1] cameras per launch;  out[2] workgroup slots of that launch;  out[3] intrinsic columns per
- * camera;  out[4] cameras;  out[5] 1 when the stereo Schur sums take four lanes per view;  out[6..7] 0.
+ * camera;  out[4] cameras;  out[5] 1 when the stereo Schur sums take four lanes per view;  out[6] 1 when a trial step that
+ * is expected to be rejected runs on a second stream beside its retry (small problems);  out[7] how many did so far.
  * ccalib_solver_time_kernels' ms[1] is the duration of ONE such launch (all out[1] cameras).
  */
 int ccalib_solver_describe(ccalib_solver* s, int out[8]);

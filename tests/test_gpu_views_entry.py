@@ -111,3 +111,40 @@ def test_stereo_views_equal_flat(pkg):
     for a, b in ((A1, got["K1"]), (A2, got["K2"]), (D1, got["d1"]), (D2, got["d2"]), (R, got["R"]), (T, got["T"]), (E, got["E"]),
                  (F, got["F"]), (rt, got["rt"])):
         assert np.array_equal(np.ravel(a), np.ravel(b))
+
+
+def test_blocks_of_finished_calls_are_reused_and_released(pkg):
+    """A finished call leaves its device blocks in the library's pool; the next call of the same shape takes them (same
+    results, to the bit), and ccalib_release_cached_memory hands everything back."""
+    cc, synth = pkg, pkg.synth
+    obj = synth.chessboard(9, 6, 25.0)
+    ms = synth.make_views(obj, 2000, 0xC0FFEE + 46)
+    cc.release_cached_memory()
+    first = cc.calibrate_camera(obj, ms.img, SIZE)
+    second = cc.calibrate_camera(obj, ms.img, SIZE)   # runs in the first call's blocks, whatever they still hold
+    _same(second, first)
+    assert cc.release_cached_memory() > 0
+    assert cc.release_cached_memory() == 0
+    _same(cc.calibrate_camera(obj, ms.img, SIZE), first)
+
+
+def test_doomed_trial_beside_its_retry_changes_nothing(pkg, monkeypatch):
+    """Small stereo problems run a trial that is expected to be rejected on a second stream beside the retry queued for
+    it: same LM record and same results as with one stream."""
+    cc, synth = pkg, pkg.synth
+    obj = synth.chessboard(9, 6, 25.0)
+    st = synth.make_stereo(obj, 3000, 0xC0FFEE + 47)
+    flags = (cc.CALIB_FIX_ASPECT_RATIO | cc.CALIB_ZERO_TANGENT_DIST | cc.CALIB_USE_INTRINSIC_GUESS | cc.CALIB_SAME_FOCAL_LENGTH |
+             cc.CALIB_RATIONAL_MODEL | cc.CALIB_FIX_K3 | cc.CALIB_FIX_K4 | cc.CALIB_FIX_K5)
+    K1 = cc.init_camera_matrix_2d(obj, st.img1, SIZE)
+    K2 = cc.init_camera_matrix_2d(obj, st.img2, SIZE)
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("CCALIB_AUX_STREAM", mode)
+        got = cc.stereo_calibrate(obj, st.img1, st.img2, K1, None, K2, None, SIZE, flags, criteria=(3, 60, 1e-7))
+        runs[mode] = (got, cc.last_lm_trace())
+    a, b = runs["1"], runs["0"]
+    assert np.array_equal(a[1][:, :7], b[1][:, :7])
+    assert a[1][:, 3].max() >= 2, "no iteration needed a retry: the second stream was never used"
+    for k in ("rms", "K1", "K2", "d1", "d2", "R", "T", "rt"):
+        assert np.array_equal(np.asarray(a[0][k]), np.asarray(b[0][k])), k
