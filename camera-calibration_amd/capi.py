@@ -69,13 +69,17 @@ def load():
         raise RuntimeError(f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` "
                            "(there is no CPU fallback)")
     lib = C.CDLL(LIB_PATH)
+    # an older build named by CCALIB_OLD_LIB_OK=1 + CCALIB_LIB (same-box A/B timing against an earlier commit) may lack
+    # the newer entry points; the in-tree library must have them all
+    older_ok = os.environ.get("CCALIB_OLD_LIB_OK") == "1" and os.environ.get("CCALIB_LIB")
     for name in SYMBOLS:
-        if not hasattr(lib, name):
+        if not hasattr(lib, name) and not older_ok:
             raise RuntimeError(f"{LIB_PATH} does not export {name}")
     lib.ccalib_last_error.restype = C.c_char_p
     lib.ccalib_version.restype = C.c_char_p
     lib.ccalib_solver_destroy.restype = None
-    lib.ccalib_release_cached_memory.restype = C.c_size_t
+    if hasattr(lib, "ccalib_release_cached_memory"):
+        lib.ccalib_release_cached_memory.restype = C.c_size_t
     _lib = lib
     return lib
 
