@@ -41,6 +41,25 @@ inline void flatten(const std::vector<std::vector<cv::Point3f>>& obj, const std:
         m.insert(m.end(), &img[i][0].x, &img[i][0].x + 2 * img[i].size());
     }
 }
+// ... or one pointer per view into the vectors themselves, for the ccalib_*_views entry points: nothing is copied here
+struct ViewPointers {
+    std::vector<int> npts;
+    std::vector<const float*> obj, img1, img2;
+};
+inline ViewPointers view_pointers(const std::vector<std::vector<cv::Point3f>>& obj, const std::vector<std::vector<cv::Point2f>>& img1,
+                                  const std::vector<std::vector<cv::Point2f>>* img2 = nullptr) {
+    static_assert(sizeof(cv::Point3f) == 3 * sizeof(float) && sizeof(cv::Point2f) == 2 * sizeof(float), "packed points");
+    CV_Assert(obj.size() == img1.size() && !obj.empty() && (!img2 || img2->size() == obj.size()));
+    ViewPointers vp;
+    for (size_t i = 0; i < obj.size(); i++) {
+        CV_Assert(obj[i].size() == img1[i].size() && !obj[i].empty() && (!img2 || (*img2)[i].size() == obj[i].size()));
+        vp.npts.push_back((int)obj[i].size());
+        vp.obj.push_back(&obj[i][0].x);
+        vp.img1.push_back(&img1[i][0].x);
+        if (img2) vp.img2.push_back(&(*img2)[i][0].x);
+    }
+    return vp;
+}
 inline cv::Mat as_f64(const cv::Mat& a, int rows, int cols, bool identity) {
     cv::Mat r = identity ? cv::Mat::eye(rows, cols, CV_64F) : cv::Mat::zeros(rows, cols, CV_64F);
     if (!a.empty()) {
@@ -62,15 +81,13 @@ inline double calibrateCamera(const std::vector<std::vector<cv::Point3f>>& objec
                               std::vector<cv::Mat>& tvecs, int flags = 0,
                               cv::TermCriteria crit = cv::TermCriteria(cv::TermCriteria::COUNT + cv::TermCriteria::EPS, 30,
                                                                        DBL_EPSILON)) {
-    std::vector<int> npts;
-    std::vector<float> o, m;
-    flatten(objectPoints, imagePoints, npts, o, m);
-    const int n = (int)npts.size(), nd = ccalib_dist_coeffs_out(flags, 0);
+    const ViewPointers vp = view_pointers(objectPoints, imagePoints);
+    const int n = (int)vp.npts.size(), nd = ccalib_dist_coeffs_out(flags, 0);
     cv::Mat K = as_f64(cameraMatrix, 3, 3, true), D = as_f64(distCoeffs, nd, 1, false), rv(n, 3, CV_64F), tv(n, 3, CV_64F);
     double rms = 0;
-    check(ccalib_calibrate_camera(n, npts.data(), o.data(), m.data(), imageSize.width, imageSize.height, K.ptr<double>(),
-                                  D.ptr<double>(), nd, rv.ptr<double>(), tv.ptr<double>(), flags, crit.type, crit.maxCount,
-                                  crit.epsilon, nullptr, &rms, nullptr));
+    check(ccalib_calibrate_camera_views(n, vp.npts.data(), vp.obj.data(), vp.img1.data(), imageSize.width, imageSize.height,
+                                        K.ptr<double>(), D.ptr<double>(), nd, rv.ptr<double>(), tv.ptr<double>(), flags, crit.type,
+                                        crit.maxCount, crit.epsilon, nullptr, &rms, nullptr));
     // prepareDistCoeffs keeps the caller's orientation: a column for an n x 1 input, a row otherwise (empty included)
     const bool column = distCoeffs.cols == 1;
     cameraMatrix = K, distCoeffs = column ? D : D.reshape(1, 1);
@@ -98,19 +115,15 @@ inline double stereoCalibrate(const std::vector<std::vector<cv::Point3f>>& objec
                               cv::Mat& R, cv::Mat& T, cv::Mat& E, cv::Mat& F, int flags = cv::CALIB_FIX_INTRINSIC,
                               cv::TermCriteria crit = cv::TermCriteria(cv::TermCriteria::COUNT + cv::TermCriteria::EPS, 30,
                                                                        1e-6)) {
-    std::vector<int> npts, npts2;
-    std::vector<float> o, m1, o2, m2;
-    flatten(objectPoints, imagePoints1, npts, o, m1);
-    flatten(objectPoints, imagePoints2, npts2, o2, m2);
-    CV_Assert(npts == npts2);
+    const ViewPointers vp = view_pointers(objectPoints, imagePoints1, &imagePoints2);
     cv::Mat K1 = as_f64(cameraMatrix1, 3, 3, true), K2 = as_f64(cameraMatrix2, 3, 3, true);
     cv::Mat D1 = as_f64(distCoeffs1, 14, 1, false), D2 = as_f64(distCoeffs2, 14, 1, false);
     R.create(3, 3, CV_64F), T.create(3, 1, CV_64F), E.create(3, 3, CV_64F), F.create(3, 3, CV_64F);
     double rms = 0;
-    check(ccalib_stereo_calibrate((int)npts.size(), npts.data(), o.data(), m1.data(), m2.data(), K1.ptr<double>(),
-                                  D1.ptr<double>(), K2.ptr<double>(), D2.ptr<double>(), imageSize.width, imageSize.height,
-                                  R.ptr<double>(), T.ptr<double>(), E.ptr<double>(), F.ptr<double>(), flags, crit.type,
-                                  crit.maxCount, crit.epsilon, nullptr, nullptr, nullptr, &rms, nullptr));
+    check(ccalib_stereo_calibrate_views((int)vp.npts.size(), vp.npts.data(), vp.obj.data(), vp.img1.data(), vp.img2.data(),
+                                        K1.ptr<double>(), D1.ptr<double>(), K2.ptr<double>(), D2.ptr<double>(), imageSize.width,
+                                        imageSize.height, R.ptr<double>(), T.ptr<double>(), E.ptr<double>(), F.ptr<double>(), flags,
+                                        crit.type, crit.maxCount, crit.epsilon, nullptr, nullptr, nullptr, &rms, nullptr));
     const int nd = ccalib_dist_coeffs_out(flags, 1);
     const bool column1 = distCoeffs1.cols == 1, column2 = distCoeffs2.cols == 1;  // orientation kept, as above
     cameraMatrix1 = K1, cameraMatrix2 = K2;

@@ -194,3 +194,21 @@ def test_full_size_100k_views_whole_call(pkg, synth):
     assert np.median(dev) < 0.01 and np.mean(dev > 0.05) < 1e-3   # a planar view now and then keeps its mirror pose
     rms2, _ = pkg.reprojection_error(obj, ms.img, got["K"], got["dist"], got["rvecs"], got["tvecs"])
     assert abs(rms2 - got["rms"]) < 1e-5 * got["rms"]
+
+
+@pytest.mark.gpu
+def test_parking_point_of_the_refinement_changes_nothing(pkg, synth, monkeypatch):
+    """The pose refinement leaves views that are still running after `cut` iterations to a second launch.  Both
+    launches give a view four lanes and the same arithmetic, so where a view is parked must not show in its pose."""
+    obj = synth.chessboard(9, 6, 25.0)
+    ms = synth.make_views(obj, 5000, 0xC0FFEE + 12)
+    cam = ms.cam
+    K = np.array([[cam.fx * 0.97, 0, cam.cx + 3], [0, cam.fy * 1.02, cam.cy - 2], [0, 0, 1.0]])
+    k14 = np.r_[cam.dist(5) * 0.8, np.zeros(9)]
+    poses = {}
+    for cut in ("1", "6", "20"):
+        monkeypatch.setenv("CCALIB_INIT_CUT", cut)
+        s = pkg.Solver(obj, ms.img)
+        poses[cut] = s.init_poses(K, k14)
+        s.close()
+    assert np.array_equal(poses["1"], poses["6"]) and np.array_equal(poses["6"], poses["20"])
