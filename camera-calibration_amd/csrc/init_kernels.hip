@@ -176,18 +176,49 @@ __device__ __forceinline__ void jacobi_rot3(double (&m)[9], double (&V)[9]) {
     }
 }
 
+// Sum over the L consecutive lanes that share a view, returned in all of them: the butterfly adds the same two
+// numbers in both lanes of a pair, so every lane of the group ends up with the same bits and takes the same branches.
+template <int L>
+__device__ __forceinline__ double group_sum(double v) {
+    static_assert(L == 1 || L == 2 || L == 4 || L == 8 || L == 16 || L == 64, "lanes per view");
+    if (L == 64) return wave_sum(v);
+    if (L >= 2) v += dpp_move<0xB1>(v);    // quad_perm [1,0,3,2]
+    if (L >= 4) v += dpp_move<0x4E>(v);    // quad_perm [2,3,0,1]
+    if (L >= 8) v += dpp_move<0x141>(v);   // row_half_mirror: lane i <-> 7 - i of each half row
+    if (L >= 16) v += dpp_move<0x140>(v);  // row_mirror: lane i <-> 15 - i of each row
+    return v;
+}
+
+// The same for the maximum.
+template <int L>
+__device__ __forceinline__ double group_max(double v) {
+    if (L == 64) {
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) v = fmax(v, __shfl_xor(v, m, 64));
+        return v;
+    }
+    if (L >= 2) v = fmax(v, dpp_move<0xB1>(v));
+    if (L >= 4) v = fmax(v, dpp_move<0x4E>(v));
+    if (L >= 8) v = fmax(v, dpp_move<0x141>(v));
+    if (L >= 16) v = fmax(v, dpp_move<0x140>(v));
+    return v;
+}
+
 // The frame cvFindExtrinsicCameraParams2 moves a planar rig into: rows of Rt are the principal axes of
 // the object points (largest spread first), Tt = -Rt * centroid.  Returns false for a non-planar rig.
-template <class Obj>
-__device__ bool board_frame(int n, Obj obj, Mat3& Rt, double Tt[3]) {
+// (L lanes share the view, as in refine_pose: lane `sub` takes points sub, sub + L, ...; every sum over points is
+// completed over the group, so all L lanes hold the same numbers.  The same holds for the homography functions below.)
+template <int L, class Obj>
+__device__ bool board_frame(int n, Obj obj, Mat3& Rt, double Tt[3], int sub) {
     double Mc[3] = {0, 0, 0};
-    for (int p = 0; p < n; p++) {
+    for (int p = sub; p < n; p += L) {
         float3 o = obj(p);
         Mc[0] += o.x, Mc[1] += o.y, Mc[2] += o.z;
     }
-    Mc[0] /= n, Mc[1] /= n, Mc[2] /= n;
+#pragma unroll
+    for (int k = 0; k < 3; k++) Mc[k] = group_sum<L>(Mc[k]) / n;
     double m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int p = 0; p < n; p++) {
+    for (int p = sub; p < n; p += L) {
         float3 o = obj(p);
         double d[3] = {o.x - Mc[0], o.y - Mc[1], o.z - Mc[2]};
 #pragma unroll
@@ -195,6 +226,10 @@ __device__ bool board_frame(int n, Obj obj, Mat3& Rt, double Tt[3]) {
 #pragma unroll
             for (int b = a; b < 3; b++) m[a * 3 + b] += d[a] * d[b];
     }
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = a; b < 3; b++) m[a * 3 + b] = group_sum<L>(m[a * 3 + b]);
     m[3] = m[1], m[6] = m[2], m[7] = m[5];
     double V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     for (int sweep = 0; sweep < 8; sweep++) {
@@ -228,9 +263,9 @@ __device__ bool board_frame(int n, Obj obj, Mat3& Rt, double Tt[3]) {
 // ---- findHomography(method 0) ----------------------------------------------------------------
 // Transfer residuals of the 8-parameter homography h (h22 = 1): sum of squares, and with WANT_J the
 // normal equations A = J^T J (packed upper 8x8), v = J^T r and max |r|.
-template <bool WANT_J, class Src, class Dst>
+template <bool WANT_J, int L, class Src, class Dst>
 __device__ __forceinline__ double homography_eval(int n, Src src, Dst dst, const double (&h)[8], double (&A)[36],
-                                                  double (&v)[8], double& rmax) {
+                                                  double (&v)[8], double& rmax, int sub) {
     double S = 0;
     if constexpr (WANT_J) {
 #pragma unroll
@@ -239,7 +274,7 @@ __device__ __forceinline__ double homography_eval(int n, Src src, Dst dst, const
         for (int k = 0; k < 8; k++) v[k] = 0;
         rmax = 0;
     }
-    for (int p = 0; p < n; p++) {
+    for (int p = sub; p < n; p += L) {
         float2 M = src(p), m = dst(p);
         double X = M.x, Y = M.y;
         double w = h[6] * X + h[7] * Y + 1.;
@@ -276,15 +311,22 @@ __device__ __forceinline__ double homography_eval(int n, Src src, Dst dst, const
             }
         }
     }
-    return S;
+    if constexpr (WANT_J) {
+#pragma unroll
+        for (int k = 0; k < 36; k++) A[k] = group_sum<L>(A[k]);
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = group_sum<L>(v[k]);
+        rmax = group_max<L>(rmax);
+    }
+    return group_sum<L>(S);
 }
 
 // cv::LMSolver::run(maxIters = 10, eps = FLT_EPSILON) on the transfer error, as findHomography polishes
 // its DLT estimate.
-template <class Src, class Dst>
-__device__ void homography_polish(int n, Src src, Dst dst, double (&x)[8]) {
+template <int LN, class Src, class Dst>
+__device__ void homography_polish(int n, Src src, Dst dst, double (&x)[8], int sub) {
     double A[36], v[8], D[8], xd[8], d[8], L[36], invd[8], rmax = 0, dummy = 0;
-    double S = homography_eval<true>(n, src, dst, x, A, v, rmax);
+    double S = homography_eval<true, LN>(n, src, dst, x, A, v, rmax, sub);
 #pragma unroll
     for (int i = 0; i < 8; i++) D[i] = A[tri<8>(i, i)];
     const double Rlo = 0.25, Rhi = 0.75;
@@ -304,7 +346,7 @@ __device__ void homography_polish(int n, Src src, Dst dst, double (&x)[8]) {
         chol_bwd<8>(L, invd, d);
 #pragma unroll
         for (int i = 0; i < 8; i++) xd[i] = x[i] - d[i];
-        double Sd = homography_eval<false>(n, src, dst, xd, L, invd, dummy);
+        double Sd = homography_eval<false, LN>(n, src, dst, xd, L, invd, dummy, sub);
         double dS = 0, t = 0, dmax = 0;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -351,32 +393,35 @@ __device__ void homography_polish(int n, Src src, Dst dst, double (&x)[8]) {
             S = Sd;
 #pragma unroll
             for (int i = 0; i < 8; i++) x[i] = xd[i];
-            homography_eval<true>(n, src, dst, x, A, v, rmax);
+            homography_eval<true, LN>(n, src, dst, x, A, v, rmax, sub);
         }
         iter++;
         if (!(iter < 10 && dmax >= kFltEps && rmax >= kFltEps)) break;
     }
 }
 
-template <class Src, class Dst>
-__device__ bool find_homography(int n, Src src, Dst dst, Mat3& H) {
+template <int L, class Src, class Dst>
+__device__ bool find_homography(int n, Src src, Dst dst, Mat3& H, int sub) {
     double cM[2] = {0, 0}, cm[2] = {0, 0}, sM[2] = {0, 0}, sm[2] = {0, 0};
-    for (int p = 0; p < n; p++) {
+    for (int p = sub; p < n; p += L) {
         float2 M = src(p), m = dst(p);
         cM[0] += M.x, cM[1] += M.y, cm[0] += m.x, cm[1] += m.y;
     }
-    cM[0] /= n, cM[1] /= n, cm[0] /= n, cm[1] /= n;
-    for (int p = 0; p < n; p++) {
+#pragma unroll
+    for (int k = 0; k < 2; k++) cM[k] = group_sum<L>(cM[k]) / n, cm[k] = group_sum<L>(cm[k]) / n;
+    for (int p = sub; p < n; p += L) {
         float2 M = src(p), m = dst(p);
         sM[0] += fabs(M.x - cM[0]), sM[1] += fabs(M.y - cM[1]);
         sm[0] += fabs(m.x - cm[0]), sm[1] += fabs(m.y - cm[1]);
     }
+#pragma unroll
+    for (int k = 0; k < 2; k++) sM[k] = group_sum<L>(sM[k]), sm[k] = group_sum<L>(sm[k]);
     if (fabs(sM[0]) < kDblEps || fabs(sM[1]) < kDblEps || fabs(sm[0]) < kDblEps || fabs(sm[1]) < kDblEps) return false;
     sM[0] = n / sM[0], sM[1] = n / sM[1], sm[0] = n / sm[0], sm[1] = n / sm[1];
     // L^T L of the 2n x 9 DLT matrix with rows (X, Y, 1, 0, 0, 0, -xX, -xY, -x), (0, 0, 0, X, Y, 1, -yX, -yY, -y):
     // four symmetric 3x3 blocks  [ A 0 Bx ; 0 A By ; Bx By C ]  over q = (XX, XY, X, YY, Y, 1)
     double qa[6] = {0, 0, 0, 0, 0, 0}, qx[6] = {0, 0, 0, 0, 0, 0}, qy[6] = {0, 0, 0, 0, 0, 0}, qc[6] = {0, 0, 0, 0, 0, 0};
-    for (int p = 0; p < n; p++) {
+    for (int p = sub; p < n; p += L) {
         float2 M = src(p), m = dst(p);
         double X = (M.x - cM[0]) * sM[0], Y = (M.y - cM[1]) * sM[1];
         double x = (m.x - cm[0]) * sm[0], y = (m.y - cm[1]) * sm[1];
@@ -385,6 +430,9 @@ __device__ bool find_homography(int n, Src src, Dst dst, Mat3& H) {
 #pragma unroll
         for (int k = 0; k < 6; k++) qa[k] += q[k], qx[k] -= x * q[k], qy[k] -= y * q[k], qc[k] += rr * q[k];
     }
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+        qa[k] = group_sum<L>(qa[k]), qx[k] = group_sum<L>(qx[k]), qy[k] = group_sum<L>(qy[k]), qc[k] = group_sum<L>(qc[k]);
     double a[45], invd[9], tr = 0;
     auto s3 = [](int i, int j) { return i <= j ? i * 3 - i * (i - 1) / 2 + (j - i) : j * 3 - j * (j - 1) / 2 + (i - j); };
 #pragma unroll
@@ -427,7 +475,7 @@ __device__ bool find_homography(int n, Src src, Dst dst, Mat3& H) {
         double x[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) x[k] = H.a[k];
-        homography_polish(n, src, dst, x);
+        homography_polish<L>(n, src, dst, x, sub);
 #pragma unroll
         for (int k = 0; k < 8; k++) H.a[k] = x[k];
         H.a[8] = 1;
@@ -496,19 +544,6 @@ __device__ __forceinline__ float2 undistort(float2 m, const CamParams& cp) {
 }
 
 }  // namespace
-
-// Sum over the L consecutive lanes that share a view, returned in all of them: the butterfly adds the same two
-// numbers in both lanes of a pair, so every lane of the group ends up with the same bits and takes the same branches.
-template <int L>
-__device__ __forceinline__ double group_sum(double v) {
-    static_assert(L == 1 || L == 2 || L == 4 || L == 8 || L == 16 || L == 64, "lanes per view");
-    if (L == 64) return wave_sum(v);
-    if (L >= 2) v += dpp_move<0xB1>(v);    // quad_perm [1,0,3,2]
-    if (L >= 4) v += dpp_move<0x4E>(v);    // quad_perm [2,3,0,1]
-    if (L >= 8) v += dpp_move<0x141>(v);   // row_half_mirror: lane i <-> 7 - i of each half row
-    if (L >= 16) v += dpp_move<0x140>(v);  // row_mirror: lane i <-> 15 - i of each row
-    return v;
-}
 
 // CvLevMarq(6 parameters) with criteria (COUNT + EPS, 20, FLT_EPSILON) on the reprojection error of one view:
 // the refinement at the end of cvFindExtrinsicCameraParams2.  L lanes share a view: lane `sub` of the group takes
@@ -598,14 +633,28 @@ __device__ bool refine_pose(int n, Obj obj, const float2* irow, const CamParams&
 }
 
 // ---- cvFindExtrinsicCameraParams2 for every view ---------------------------------------------
+// Lanes per view in the homography kernels (k_init_pose, k_init_intrinsics): the sums over a view's points can be split
+// over L lanes (everything else -- the 9x9 and 8x8 factorisations, the polar iteration -- each lane then does for
+// itself).  Measured with L = 4 at 100 000 views: k_init_pose 436 -> 349 us, k_init_intrinsics 417 -> 295 us; a whole
+// calibrateCamera call at 1 000 views 2.52 -> 2.32 ms, at 20 views 2.2 -> 1.8 ms.  But findHomography's polish stops
+// on steps of FLT_EPSILON size, so a homography is only determined to about 1e-10 by its input, and with the sums taken
+// in another order than a serial loop takes them the starting poses move by that much: the residual sum of the first LM
+// iteration then agrees with a serial implementation to 1.3e-9 instead of 1e-10 on a 30-view input.  One lane keeps
+// the serial order.  -DCCALIB_INIT_LANES=4 builds the split version.
+#ifndef CCALIB_INIT_LANES
+#define CCALIB_INIT_LANES 1
+#endif
+constexpr int kInitLanes = CCALIB_INIT_LANES;
+
 template <bool RAT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_init_pose(InitArgs a, CamParams cp, double* __restrict__ pose, int* __restrict__ status, Parked parked) {
-    const int lane = threadIdx.x;
+    constexpr int L = kInitLanes;
+    const int lane = threadIdx.x, sub = lane % L, slot = lane / L;
     const int v0 = blockIdx.x * a.VPB;
     const int nv = min(a.VPB, a.nviews - v0);
     const Stage st = stage_layout(a, true);
-    const bool live = lane < nv;
-    const int row = live ? lane : 0;  // idle lanes shadow view 0 of the workgroup and store nothing
+    const bool live = slot < nv;
+    const int row = live ? slot : 0;  // idle lanes shadow view 0 of the workgroup and store nothing
     const int v = v0 + row;
     const int n = a.off[v + 1] - a.off[v];
     auto view_of = [&](int j) { return v0 + j; };
@@ -616,7 +665,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     auto obj = [&](int p) { return make_float3(ob[3 * p], ob[3 * p + 1], ob[3 * p + 2]); };
     Mat3 Rt;
     double Tt[3];
-    bool planar = board_frame(n, obj, Rt, Tt);
+    bool planar = board_frame<L>(n, obj, Rt, Tt, sub);
     // source points of the homography: the rig in its own plane, rounded to float (findHomography
     // converts its inputs to Point2f)
     float2* srow = a.shared_board ? st.src : st.src + row * st.PS;
@@ -627,7 +676,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                                   (float)(Rt.a[3] * o.x + Rt.a[4] * o.y + Rt.a[5] * o.z + Tt[1]));
         }
     } else if (live) {
-        for (int p = 0; p < n; p++) {
+        for (int p = sub; p < n; p += L) {
             float3 o = obj(p);
             srow[p] = make_float2((float)(Rt.a[0] * o.x + Rt.a[1] * o.y + Rt.a[2] * o.z + Tt[0]),
                                   (float)(Rt.a[3] * o.x + Rt.a[4] * o.y + Rt.a[5] * o.z + Tt[1]));
@@ -644,7 +693,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     auto dst = [&](int p) { return irow[p]; };
     Mat3 H, Rm;
     double ps[6];
-    bool ok = planar && find_homography(n, src, dst, H);
+    bool ok = planar && find_homography<L>(n, src, dst, H, sub);
 #pragma unroll
     for (int k = 0; k < 9; k++) ok = ok && isfinite(H.a[k]);
     if (ok) {
@@ -671,7 +720,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         ps[3] = ps[4] = ps[5] = 0;
     }
     rodrigues_m2v_polar(Rm, ps);
-    if (live) {
+    if (live && sub == 0) {
 #pragma unroll
         for (int k = 0; k < 6; k++) pose[6 * (size_t)v + k] = planar ? ps[k] : 0.;
         status[v] = planar ? 0 : 1;
@@ -683,7 +732,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // 64 / L views per wavefront (a.VPB of them staged; lanes past that shadow the workgroup's first view and store
 // nothing).  The resuming grid covers the worst case; workgroups past the parked count leave.
 #ifndef CCALIB_REFINE_WAVES
-#define CCALIB_REFINE_WAVES 3  // wavefronts per SIMD the register budget of the refinement is set for
+#define CCALIB_REFINE_WAVES 2  // wavefronts per SIMD the register budget of the refinement is set for (3: spills, no faster)
 #endif
 template <bool RAT, int L, bool RESUME>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CCALIB_REFINE_WAVES, CCALIB_REFINE_WAVES))) void k_refine_pose(InitArgs a, CamParams cp, double* __restrict__ pose, int* __restrict__ status,
@@ -730,13 +779,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CCALIB_REFIN
 
 // ---- cvInitIntrinsicParams2D: the two rows every view contributes to the 2-unknown least squares for
 // (1/fx^2, 1/fy^2); part receives per workgroup the sums  a0 a0, a0 a1, a1 a1, a0 b, a1 b.
-__global__ __launch_bounds__(64) void k_init_intrinsics(InitArgs a, double cx, double cy, double* __restrict__ part) {
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_init_intrinsics(InitArgs a, double cx, double cy,
+                                                                                                    double* __restrict__ part) {
+    constexpr int L = kInitLanes;
+    const int lane = threadIdx.x, sub = lane % L, slot = lane / L;
     const int v0 = blockIdx.x * a.VPB;
     const int nv = min(a.VPB, a.nviews - v0);
     const Stage st = stage_layout(a, false);
-    const bool live = lane < nv;
-    const int row = live ? lane : 0;
+    const bool live = slot < nv;
+    const int row = live ? slot : 0;
     const int v = v0 + row;
     const int n = a.off[v + 1] - a.off[v];
     auto view_of = [&](int j) { return v0 + j; };
@@ -748,7 +799,7 @@ __global__ __launch_bounds__(64) void k_init_intrinsics(InitArgs a, double cx, d
     auto src = [&](int p) { return make_float2(ob[3 * p], ob[3 * p + 1]); };
     auto dst = [&](int p) { return irow[p]; };
     Mat3 H;
-    bool ok = find_homography(n, src, dst, H) && live;
+    bool ok = find_homography<L>(n, src, dst, H, sub) && live && sub == 0;  // one lane of the group speaks for the view
 #pragma unroll
     for (int c = 0; c < 3; c++) H.a[c] -= H.a[6 + c] * cx, H.a[3 + c] -= H.a[6 + c] * cy;
     double h[3], vv[3], d1[3], d2[3], nn[4] = {0, 0, 0, 0};
@@ -815,7 +866,7 @@ bool init_geometry(InitArgs& a, bool with_src) {
     a.PS = a.maxnp | 1;
     a.cut = 6;
     if (const char* e = std::getenv("CCALIB_INIT_CUT")) a.cut = std::max(1, std::atoi(e));
-    for (int vpb = 64; vpb >= 1; vpb--) {
+    for (int vpb = 64 / kInitLanes; vpb >= 1; vpb--) {
         size_t bytes = sizeof(float) * init_lds_floats(a.shared_board != 0, a.board_np, a.PS, vpb, with_src);
         if (bytes <= cap) {
             a.VPB = vpb;

@@ -15,7 +15,7 @@ struct InitArgs {
     int board_np;
     int maxnp;           // largest point count of any view
     int PS;              // LDS row length in points (odd), set by init_geometry
-    int VPB;             // views per workgroup (one lane each, <= 64), set by init_geometry
+    int VPB;             // views per workgroup (a few lanes each), set by init_geometry
     unsigned lds_bytes;  // dynamic LDS per workgroup, set by init_geometry
     int cut;             // pose refinement: iterations after which a view still running is parked, set by init_geometry
 };
