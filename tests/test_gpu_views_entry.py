@@ -148,3 +148,30 @@ def test_doomed_trial_beside_its_retry_changes_nothing(pkg, monkeypatch):
     assert a[1][:, 3].max() >= 2, "no iteration needed a retry: the second stream was never used"
     for k in ("rms", "K1", "K2", "d1", "d2", "R", "T", "rt"):
         assert np.array_equal(np.asarray(a[0][k]), np.asarray(b[0][k])), k
+
+
+def test_poses_come_back_whole_when_they_take_several_staging_rounds(pkg):
+    """400 000 views: the refined poses (19 MB) leave the device in two rounds through the pinned staging buffers and are
+    split into rvecs / tvecs on the way; the solver-level download of the same run must hold the same numbers."""
+    cc, synth = pkg, pkg.synth
+    obj = synth.chessboard(4, 3, 30.0)
+    ms = synth.make_views(obj, 40000, 0xC0FFEE + 49)
+    img = np.ascontiguousarray(np.tile(ms.img, (10, 1, 1)))
+    N = img.shape[0]
+    got = cc.calibrate_camera(obj, img, SIZE, criteria=(3, 3, 1e-12))
+    assert got["iters"] == 3 and np.isfinite(got["rvecs"]).all() and np.isfinite(got["tvecs"]).all()
+    # the ten copies of every view end at the same pose, and no row was left unwritten or shifted
+    rv, tv = got["rvecs"].reshape(10, -1, 3), got["tvecs"].reshape(10, -1, 3)
+    assert np.array_equal(rv[0], rv[9]) and np.array_equal(tv[0], tv[9]) and np.array_equal(rv[3], rv[6])
+    assert np.abs(tv[0][:, 2]).min() > 1.0
+    # the same problem through the solver level (one hipMemcpy-shaped download of r|t rows)
+    s = cc.Solver(obj, img)
+    K0 = s.init_intrinsics(SIZE)
+    s.init_poses(K0, None, want=False)
+    intr, mask, _ = cc.mono_start(K0, np.zeros(5), 0)
+    s.set_start(intr, mask, None)
+    s.run(criteria=(3, 3, 1e-12))
+    out = s.get()
+    s.close()
+    assert np.array_equal(out["rt"][:, :3], got["rvecs"]) and np.array_equal(out["rt"][:, 3:], got["tvecs"])
+    assert N == 400000
