@@ -779,6 +779,7 @@ __global__ __launch_bounds__(64) void k_schur(const double* blk, int npad, int n
     for (int i = 0; i < NC; i++)
 #pragma unroll
         for (int b = 0; b < 6; b++) Z[i][b] = blk[blk_index(NB, 27 + 6 * i + b, vv)];
+    __builtin_amdgcn_sched_barrier(0);  // ... and the scheduler is not to sink them back among it
     bool ok = chol6(Vu, lambda, L, invd) && live;
     chol6_fwd(L, invd, y);
 #pragma unroll
@@ -825,11 +826,20 @@ __global__ __launch_bounds__(64) void k_backsub(const double* blk, int npad, int
     for (int k = 0; k < 21; k++) Vu[k] = blk[blk_index(NB, k, vv)];
 #pragma unroll
     for (int k = 0; k < 6; k++) rhs[k] = blk[blk_index(NB, 21 + k, vv)];
+    double Wv[NC][6];  // all of the view's loads first, one memory round trip for the kernel
+#pragma unroll
+    for (int i = 0; i < NC; i++)
+#pragma unroll
+        for (int b = 0; b < 6; b++) Wv[i][b] = blk[blk_index(NB, 27 + 6 * i + b, vv)];
+    double prev_in[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) prev_in[k] = pose_prev[6 * (size_t)vv + k];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < NC; i++) {
         double d = dc.v[i];
 #pragma unroll
-        for (int b = 0; b < 6; b++) rhs[b] -= blk[blk_index(NB, 27 + 6 * i + b, vv)] * d;
+        for (int b = 0; b < 6; b++) rhs[b] -= Wv[i][b] * d;
     }
     bool ok = chol6(Vu, lambda, L, invd);
     chol6_fwd(L, invd, rhs);
@@ -840,7 +850,7 @@ __global__ __launch_bounds__(64) void k_backsub(const double* blk, int npad, int
     double dn = 0, pn = 0, pnew[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) {
-        double pv = pose_prev[6 * (size_t)vv + k];
+        double pv = prev_in[k];
         double d = ok ? rhs[k] : 0.;  // a singular view block gets no update
         pnew[k] = pv - d;
         dn += d * d;
