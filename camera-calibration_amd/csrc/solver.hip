@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <climits>
 #include <mutex>
 #include <vector>
 
@@ -1345,7 +1346,10 @@ int pool_device_alloc(int device, size_t bytes, char** out, size_t* got) {
         return CCALIB_OK;
     }
     hipError_t e = hipMalloc(out, bytes);
-    if (e == hipErrorOutOfMemory && g_pool.trim() > 0) e = hipMalloc(out, bytes);  // the cache gives way to a live request
+    if (e == hipErrorOutOfMemory && g_pool.trim() > 0) {  // the cache gives way to a live request
+        (void)hipGetLastError();                          // (the failed attempt is not to be reported by a later check)
+        e = hipMalloc(out, bytes);
+    }
     HIP_TRY(e);
     return CCALIB_OK;
 }
@@ -1370,6 +1374,12 @@ struct Staging {
     static constexpr size_t kFloats = 2u << 20;  // 8 MB each
 };
 Staging g_staging;
+// with g_staging.mu held: the two buffers exist (portable: usable from every device of the process)
+int staging_ready() {
+    for (int b = 0; b < 2; b++)
+        if (!g_staging.buf[b]) HIP_TRY(hipHostMalloc(&g_staging.buf[b], sizeof(float) * Staging::kFloats, hipHostMallocPortable));
+    return CCALIB_OK;
+}
 
 // Copies the points of all views -- `fpp` floats per point, view i's at src.ptrs[i] or, for one flat array, at
 // src.flat + fpp * off[i] -- into device memory at dst, view after view.  The host side gathers chunk k + 1 into pinned
@@ -1378,8 +1388,7 @@ int upload_views(ccalib_solver* s, float* dst, const HostViews& src, int fpp, co
     const int nviews = (int)off.size() - 1;
     const size_t total = (size_t)fpp * off[nviews];
     std::lock_guard<std::mutex> lock(g_staging.mu);
-    for (int b = 0; b < 2; b++)
-        if (!g_staging.buf[b]) HIP_TRY(hipHostMalloc(&g_staging.buf[b], sizeof(float) * Staging::kFloats, hipHostMallocDefault));
+    if (int rc = staging_ready()) return rc;
     hipEvent_t ev[2] = {nullptr, nullptr};
     struct EvGuard {
         hipEvent_t* e;
@@ -1451,6 +1460,8 @@ int solver_create_views(ccalib_solver** out, int device, int ncams, int nviews, 
         if (npts[i] < 4) return set_error(CCALIB_ERR_ARG, "view %d has %d points (at least 4 needed)", i, npts[i]);
         if (shared_board && npts[i] != npts[0])
             return set_error(CCALIB_ERR_ARG, "shared_board needs the same point count in every view");
+        if (npts[i] > INT_MAX / 4 - off[i])  // point indices (and 3 x them, in floats of a view's run) are ints
+            return set_error(CCALIB_ERR_ARG, "more than %d points in all: not supported", INT_MAX / 4);
         off[i + 1] = off[i] + npts[i];
         s->maxnp = std::max(s->maxnp, npts[i]);
     }
@@ -1608,8 +1619,7 @@ int download(ccalib_solver* s, void* dst, const void* src, size_t bytes) {
         return CCALIB_OK;
     }
     std::lock_guard<std::mutex> lock(g_staging.mu);
-    for (int b = 0; b < 2; b++)
-        if (!g_staging.buf[b]) HIP_TRY(hipHostMalloc(&g_staging.buf[b], sizeof(float) * Staging::kFloats, hipHostMallocDefault));
+    if (int rc = staging_ready()) return rc;
     const size_t chunk = std::min<size_t>(sizeof(float) * Staging::kFloats, 2u << 20);  // small pieces: the unpacking overlaps
     const int nthreads = std::max(1, std::min(8, omp_get_max_threads()));
     const size_t nchunks = (bytes + chunk - 1) / chunk;
@@ -1648,8 +1658,7 @@ int solver_get_poses_split(ccalib_solver* s, double* rvecs, double* tvecs) {
     if (!s || !s->started || !rvecs || !tvecs) return set_error(CCALIB_ERR_STATE, "poses requested before set_start");
     HIP_TRY(hipSetDevice(s->device));
     std::lock_guard<std::mutex> lock(g_staging.mu);
-    for (int b = 0; b < 2; b++)
-        if (!g_staging.buf[b]) HIP_TRY(hipHostMalloc(&g_staging.buf[b], sizeof(float) * Staging::kFloats, hipHostMallocDefault));
+    if (int rc = staging_ready()) return rc;
     const size_t per_buf = sizeof(float) * Staging::kFloats / (6 * sizeof(double));  // views one buffer holds
     [[maybe_unused]] const int nthreads = std::max(1, std::min(8, omp_get_max_threads()));
     for (size_t v0 = 0; v0 < (size_t)s->nviews; v0 += 2 * per_buf) {
