@@ -1,4 +1,4 @@
-# Copies the summaries tools/gpu_round3.sh left under gpurun_out/ into profiles/ under this round's names.
+# Copies the summaries tools/gpu_round3.sh left under gpurun_out/ into profiles/ under the given prefix (default r03).
 set -e
 R=${1:-r03}
 cp gpurun_out/bench.json profiles/${R}_bench.json
@@ -12,7 +12,7 @@ cp gpurun_out/pmc_stereo.json profiles/${R}_stereo_pmc.json
 python3 - "$R" <<'PY'
 import json, sys
 R = sys.argv[1]
-json.dump({"this build": json.load(open("gpurun_out/sq_r03.json")), "round 2 build": json.load(open("gpurun_out/sq_r02.json")),
+json.dump({"this build": json.load(open("gpurun_out/sq_r03.json")), "build of commit a4f74dc": json.load(open("gpurun_out/sq_r02.json")),
            "note": "rocprofv3 --pmc over tools/kernel_bench.py 100000 20 (the mono fused Jacobian kernel launched back to back), "
                    "one pass each; per-kernel means over the launches"}, open("profiles/%s_sq_active_before_after.json" % R, "w"), indent=1)
 PY
