@@ -120,3 +120,26 @@ def test_a_view_with_unusable_blocks_counts_for_nothing_in_both_sum_kernels(pkg,
     S2, b2 = s.reduce(1e-3, 24)
     s.close()
     assert np.allclose(S0, S2, rtol=1e-9, atol=1e-10 * np.abs(S2).max()) and np.allclose(b0, b2, rtol=1e-9, atol=1e-10 * np.abs(b2).max())
+
+
+def test_config5_shape_10k_pairs_against_schur_oracle(pkg, orc, synth):
+    """The shape of BASELINE configs[4] -- 17x12 board, 204 points per view (four chunks of 56 in the fused kernel), nine
+    free intrinsics per camera -- at a size the Schur oracle finishes in seconds: whole stereoCalibrate calls,
+    initialisation included on both sides."""
+    obj = synth.chessboard(17, 12, 10.0)
+    st = synth.make_stereo(obj, 10_000, 0xC0FFEE + 6)
+    K1 = pkg.init_camera_matrix_2d(obj, st.img1, (640, 480))
+    K2 = pkg.init_camera_matrix_2d(obj, st.img2, (640, 480))
+    flags = pkg.CALIB_USE_INTRINSIC_GUESS
+    crit = (3, 40, 1e-8)
+    got = pkg.stereo_calibrate(obj, st.img1, st.img2, K1, None, K2, None, (640, 480), flags, criteria=crit)
+    ref = orc.stereo_calibrate(obj, st.img1, st.img2, K1, None, K2, None, (640, 480), flags, criteria=crit, schur=True,
+                               nthreads=min(16, os.cpu_count() or 1))
+    assert abs(got["rms"] - ref["rms"]) <= REL * ref["rms"]
+    assert abs(got["iters"] - ref["iters"]) <= 1
+    for key in ("K1", "K2", "R", "T", "E", "F"):
+        assert np.allclose(got[key], ref[key], rtol=REL, atol=1e-8 * np.abs(ref[key]).max()), key
+    assert np.allclose(got["d1"], ref["d1"], rtol=REL, atol=1e-9)
+    assert np.allclose(got["d2"], ref["d2"], rtol=REL, atol=1e-9)
+    assert np.abs(got["rt"] - ref["rt"])[:, :3].max() < 1e-6
+    assert np.abs(got["rt"] - ref["rt"])[:, 3:].max() < 1e-6 * np.abs(ref["rt"][:, 3:]).max()
