@@ -146,3 +146,41 @@ def test_hip_takes_the_oracles_decisions_config2_1k_views(pkg, orc, synth):
     k = assert_same_decisions(tr, ref["trace"], "configs[1]")
     assert k >= 5
     assert abs(got["rms"] - ref["rms"]) <= 1e-9 * ref["rms"]
+
+
+@pytest.mark.gpu
+def test_hip_takes_the_oracles_decisions_config3_10k_pairs(pkg, orc, synth):
+    """BASELINE configs[2] at its stated 10 000 pairs with the reference's flag set and criteria
+    (binocular_chessboard.cpp:152-162): the LM record of the whole stereoCalibrate call against the Schur oracle's."""
+    import os
+    obj = synth.chessboard(9, 6, 25.0)
+    st = synth.make_stereo(obj, 10_000, 0xC0FFEE + 3)
+    K1 = pkg.init_camera_matrix_2d(obj, st.img1, (640, 480))
+    K2 = pkg.init_camera_matrix_2d(obj, st.img2, (640, 480))
+    flags = (pkg.CALIB_FIX_ASPECT_RATIO | pkg.CALIB_ZERO_TANGENT_DIST | pkg.CALIB_USE_INTRINSIC_GUESS |
+             pkg.CALIB_SAME_FOCAL_LENGTH | pkg.CALIB_RATIONAL_MODEL | pkg.CALIB_FIX_K3 | pkg.CALIB_FIX_K4 |
+             pkg.CALIB_FIX_K5)
+    crit = (3, 100, 1e-5)
+    got = pkg.stereo_calibrate(obj, st.img1, st.img2, K1, None, K2, None, (640, 480), flags, criteria=crit)
+    tr = pkg.last_lm_trace()
+    assert tr.shape[0] == got["iters"]
+    ref = orc.stereo_calibrate(obj, st.img1, st.img2, K1, None, K2, None, (640, 480), flags, criteria=crit, schur=True,
+                               nthreads=min(16, os.cpu_count() or 1), trace=True)
+    k = assert_same_decisions(tr, ref["trace"], "configs[2]")
+    assert k >= 20
+
+
+@pytest.mark.gpu
+def test_hip_takes_the_oracles_decisions_config4_100k_views(pkg, orc, synth):
+    """BASELINE configs[3] at its stated 100 000 views, cv::calibrateCamera's default criteria: record for record
+    against the Schur oracle on sixteen threads."""
+    import os
+    obj = synth.chessboard(9, 6, 25.0)
+    ms = synth.make_views(obj, 100_000, 0xC0FFEE + 4)
+    got = pkg.calibrate_camera(obj, ms.img, (640, 480))
+    tr = pkg.last_lm_trace()
+    assert tr.shape[0] == got["iters"]
+    ref = orc.calibrate_camera(obj, ms.img, (640, 480), schur=True, nthreads=min(16, os.cpu_count() or 1), trace=True)
+    k = assert_same_decisions(tr, ref["trace"], "configs[3]")
+    assert k >= 5
+    assert abs(got["rms"] - ref["rms"]) <= 1e-9 * ref["rms"]
