@@ -302,11 +302,13 @@ int submit_reduction(ccalib_solver* s, int n, const LmCtrl* ctrl, LmStepArgs* st
     const int q = s->slot;
     const unsigned long long seq = ++s->seq;
     // Publishing from the last workgroup of the column-sum kernel saves a kernel boundary (~3 us) but costs every
-    // workgroup a device-wide fence and an atomic on one counter (~35 ns each, serialised): past a few hundred
-    // columns a publishing kernel of its own is cheaper (499 columns: 25.1 us against 8.9 + 3.9).
+    // workgroup a device-wide fence and an atomic on one counter (serialised; the fence writes the XCD's L2 back):
+    // past a few dozen columns a publishing kernel of its own is cheaper (499 columns: 25.1 us against 8.9 + 3.9; the
+    // 111 columns of a monocular Jacobian pass: 0.1536 against 0.1515 ms per iteration; the 3 or 4 of a trial step
+    // are better off in one kernel).
     int ncol = 0;
     for (int i = 0; i < s->segs.nseg; i++) ncol += s->segs.seg[i].n;
-    const bool split = s->split_publish >= 0 ? s->split_publish != 0 : ncol >= 160;
+    const bool split = s->split_publish >= 0 ? s->split_publish != 0 : ncol >= 64;
     if (step) {
         step->red = s->d_red[q], step->n = n, step->hred = s->h_red[q], step->flag = s->h_flag[q], step->seq = seq;
         step->cin = ctrl;
