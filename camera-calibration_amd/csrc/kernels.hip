@@ -875,9 +875,13 @@ __global__ __launch_bounds__(64) void k_backsub(const double* blk, int npad, int
 // device memory.  With `flag` set, the last workgroup to finish copies out[0..n_out) to host_out (pinned host
 // memory) in one piece and then stores `seq` to *flag (also pinned), which a polling host thread takes as "all sums
 // have landed": one burst over the bus instead of one 8-byte write and one system-wide fence per workgroup.
+// With `pairs` (pinned host memory, 16 bytes per sum) every workgroup sends its sum there itself, together with the
+// pass's sequence number, in one 16-byte store: a host that finds the number beside a sum has the sum.  No fence, no
+// counter, no last workgroup -- the host waits for all the numbers instead of for one flag.
 __global__ __launch_bounds__(kBlock) void k_colsum(ColsumArgs a, double* out, unsigned* counter, double* host_out, int n_out,
                                                    volatile unsigned long long* flag, unsigned long long seq,
-                                                   const LmCtrl* __restrict__ ctrl, LmStepArgs st, int has_step) {
+                                                   const LmCtrl* __restrict__ ctrl, LmStepArgs st, int has_step,
+                                                   double2* __restrict__ pairs) {
     __shared__ double sm[kWaves];
     __shared__ int is_last;
     if (ctrl && !ctrl->go) return;
@@ -904,6 +908,8 @@ __global__ __launch_bounds__(kBlock) void k_colsum(ColsumArgs a, double* out, un
         double tot = sm[0];
         for (int ww = 1; ww < kWaves; ww++) tot += sm[ww];
         out[sg.out_ofs + k] = tot;
+        // (the second word is the sum's bits XOR the number: a host that saw a new half beside an old one could tell)
+        if (pairs) pairs[sg.out_ofs + k] = make_double2(tot, __longlong_as_double(__double_as_longlong(tot) ^ (long long)seq));
         is_last = 0;
         if (flag || has_step) {
             __threadfence();
@@ -1082,13 +1088,13 @@ void launch_reproj(const PassArgs& a, const CamParams& cp, bool rational, int gr
 }
 
 void launch_colsum(const ColsumArgs& a, double* out, unsigned* counter, double* host_out, int n_out, unsigned long long* flag,
-                   unsigned long long seq, hipStream_t st, const LmCtrl* ctrl, const LmStepArgs* step) {
+                   unsigned long long seq, hipStream_t st, const LmCtrl* ctrl, const LmStepArgs* step, double2* pairs) {
     int total = 0;
     for (int i = 0; i < a.nseg; i++) total += a.seg[i].n;
     static const LmStepArgs none = {};
     if (total > 0)
         hipLaunchKernelGGL(k_colsum, dim3(total), dim3(kBlock), 0, st, a, out, counter, host_out, n_out, flag, seq, ctrl,
-                           step ? *step : none, step ? 1 : 0);
+                           step ? *step : none, step ? 1 : 0, pairs);
 }
 
 void launch_publish(const double* src, int n, double* dst, unsigned long long* flag, unsigned long long seq, hipStream_t st) {

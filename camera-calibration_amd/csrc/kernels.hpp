@@ -129,7 +129,8 @@ struct ColsumArgs {
 // host_out and raises the flag.  With `step`, it instead runs the LM step prediction on the sums (step->red == out)
 // and publishes through step->hred / step->flag.
 void launch_colsum(const ColsumArgs&, double* out, unsigned* counter, double* host_out, int n_out, unsigned long long* flag,
-                   unsigned long long seq, hipStream_t, const LmCtrl* ctrl = nullptr, const LmStepArgs* step = nullptr);
+                   unsigned long long seq, hipStream_t, const LmCtrl* ctrl = nullptr, const LmStepArgs* step = nullptr,
+                   double2* pairs = nullptr);  // pairs (pinned, 16 bytes per sum): every workgroup sends {sum, seq} itself
 void launch_publish(const double* src, int n, double* dst, unsigned long long* flag, unsigned long long seq, hipStream_t);
 int pass_block_size();
 // dynamic LDS one workgroup of the per-point kernels needs

@@ -54,6 +54,12 @@ struct Pending {
     int slot = 0;
     unsigned long long seq = 0;
     hipStream_t stream = nullptr;  // the stream the reduction was submitted to
+    // direct publication (every column-sum workgroup writes {sum, seq} to pinned memory): the ranges of sums to wait for
+    bool direct = false;
+    int nrange = 0;
+    struct Range {
+        int ofs, n;
+    } range[kMaxColsumSegs];
 };
 
 struct ccalib_solver {
@@ -124,6 +130,8 @@ struct ccalib_solver {
     double* d_red[2] = {nullptr, nullptr};
     double* h_red[2] = {nullptr, nullptr};                     // pinned, device-writable
     unsigned long long* h_flag[2] = {nullptr, nullptr};        // pinned
+    double2* h_pair[2] = {nullptr, nullptr};                   // pinned: {sum, sequence number} per sum, written by k_colsum
+    bool direct_sums = true;                                   // CCALIB_DIRECT_SUMS=0: publish through a flag
     unsigned* d_counter = nullptr;
     unsigned long long seq = 0;
     double wait_limit_s = 120.;         // longest wait for one pass's sums (CCALIB_WAIT_LIMIT_S)
@@ -300,7 +308,11 @@ int queue_colsum(ccalib_solver* s, const double* part, int nrows, int n, int out
 // return at once when the iteration was called off), else null.
 int submit_reduction(ccalib_solver* s, int n, const LmCtrl* ctrl, LmStepArgs* step, Pending* out) {
     const int q = s->slot;
-    const unsigned long long seq = ++s->seq;
+    // process-wide numbers: pinned blocks are reused by later solvers, and a number an earlier one left beside a sum
+    // must never be taken for this pass's
+    static std::atomic<unsigned long long> g_seq{0};
+    const unsigned long long seq = s->seq = ++g_seq;
+    out->direct = false, out->nrange = 0;
     // Publishing from the last workgroup of the column-sum kernel saves a kernel boundary (~3 us) but costs every
     // workgroup a device-wide fence and an atomic on one counter (serialised; the fence writes the XCD's L2 back):
     // past a few dozen columns a publishing kernel of its own is cheaper (499 columns: 25.1 us against 8.9 + 3.9; the
@@ -325,6 +337,13 @@ int submit_reduction(ccalib_solver* s, int n, const LmCtrl* ctrl, LmStepArgs* st
         launch_colsum(s->segs, s->d_red[q], s->d_counter, nullptr, 0, nullptr, 0, s->stream, ctrl);
         NCCL_TRY(ncclAllReduce(s->d_red[q], s->d_red[q], n, ncclDouble, ncclSum, s->comm, s->stream));
         launch_publish(s->d_red[q], n, s->h_red[q], s->h_flag[q], seq, s->stream);
+    } else if (s->direct_sums && !ctrl && ncol < 256) {  // (beyond a few hundred sums one burst from a publishing kernel is as fast)
+        // one GPU, plain pass: no flag at all.  Every workgroup of the column-sum kernel sends its sum and the pass's
+        // number to pinned memory in one 16-byte store; the host waits until every sum it expects carries the number.
+        launch_colsum(s->segs, s->d_red[q], s->d_counter, nullptr, 0, nullptr, seq, s->stream, nullptr, nullptr, s->h_pair[q]);
+        out->direct = true;
+        out->nrange = s->segs.nseg;
+        for (int i = 0; i < s->segs.nseg; i++) out->range[i] = Pending::Range{s->segs.seg[i].out_ofs, s->segs.seg[i].n};
     } else if (split) {
         launch_colsum(s->segs, s->d_red[q], s->d_counter, nullptr, 0, nullptr, 0, s->stream, ctrl);
         launch_publish(s->d_red[q], n, s->h_red[q], s->h_flag[q], seq, s->stream);
@@ -344,12 +363,28 @@ int wait_reduction(ccalib_solver* s, const Pending& p, int n) {
     auto tw0 = std::chrono::steady_clock::now();
     s->t_enqueue += std::chrono::duration<double>(tw0 - s->t_enter).count();
     volatile unsigned long long* flag = s->h_flag[p.slot];
-    for (unsigned spins = 0; *flag != p.seq; spins++) {
+    // direct publication: sum i has arrived when the two words of its pair differ by exactly this pass's number.
+    // A pair caught half-way between two passes cannot pass for new with an old sum: with y old, x ^ y == seq needs
+    // x == x_old ^ seq_old ^ seq, which is not x_old (the numbers differ), and with y new it needs x == x_new.
+    const volatile unsigned long long* pairs = reinterpret_cast<const volatile unsigned long long*>(s->h_pair[p.slot]);
+    int ri = 0, rk = 0;  // next sum to wait for: range ri, entry rk
+    auto arrived = [&]() {
+        if (!p.direct) return *flag == p.seq;
+        for (; ri < p.nrange; ri++, rk = 0)
+            for (; rk < p.range[ri].n; rk++) {
+                const int i = p.range[ri].ofs + rk;
+                const unsigned long long x = pairs[2 * i], y = pairs[2 * i + 1];
+                if ((x ^ y) != p.seq) return false;
+                std::memcpy(&s->h_red[p.slot][i], &x, sizeof(double));
+            }
+        return true;
+    };
+    for (unsigned spins = 0; !arrived(); spins++) {
         if ((spins & 0xffff) == 0xffff) {  // a failed launch or a fault must not leave the host spinning
             hipError_t q = hipStreamQuery(p.stream ? p.stream : s->stream);
             if (q != hipSuccess && q != hipErrorNotReady)
                 return set_error(CCALIB_ERR_HIP, "stream failed while waiting for a reduction: %s", hipGetErrorString(q));
-            if (q == hipSuccess && *flag != p.seq) return set_error(CCALIB_ERR_HIP, "reduction finished without publishing");
+            if (q == hipSuccess && !arrived()) return set_error(CCALIB_ERR_HIP, "reduction finished without publishing");
             // nor must a peer that left a sharded run (its all-reduce never completes): bounded wait
             if (std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count() > s->wait_limit_s)
                 return set_error(CCALIB_ERR_HIP, "no reduction result after %.0f s (a rank of a sharded run may have stopped)",
@@ -1570,14 +1605,18 @@ int solver_create_views(ccalib_solver** out, int device, int ncams, int nviews, 
         if ((rc = upload_views(s, reinterpret_cast<float*>(s->d_img[c]), imgs[c], 2, off))) return rc;
     {   // both slots' sums and flags in one pinned block; coherent (uncached on the device side): the host reads
         // these while the stream that writes them is still running
-        const size_t per = sizeof(double) * ccalib_solver::kRedCap + 256;
+        const size_t per = sizeof(double) * ccalib_solver::kRedCap + 256 + sizeof(double2) * ccalib_solver::kRedCap;
         s->pinned = static_cast<char*>(g_pool.take(device, BlockPool::kPinned, 2 * per, nullptr));
-        if (!s->pinned) HIP_TRY(hipHostMalloc(&s->pinned, 2 * per, hipHostMallocCoherent));
+        if (!s->pinned) {
+            HIP_TRY(hipHostMalloc(&s->pinned, 2 * per, hipHostMallocCoherent));
+            std::memset(s->pinned, 0, 2 * per);  // no pair of words in it may differ by a sequence number by accident
+        }
         s->pinned_bytes = 2 * per;
         for (int q = 0; q < 2; q++) {
             s->h_red[q] = reinterpret_cast<double*>(s->pinned + q * per);
             s->h_flag[q] = reinterpret_cast<unsigned long long*>(s->pinned + q * per + sizeof(double) * ccalib_solver::kRedCap);
             *s->h_flag[q] = 0;
+            s->h_pair[q] = reinterpret_cast<double2*>(s->pinned + q * per + sizeof(double) * ccalib_solver::kRedCap + 256);
         }
     }
     std::memset(&s->h_maps, 0, sizeof(LmMaps));
@@ -1585,6 +1624,7 @@ int solver_create_views(ccalib_solver** out, int device, int ncams, int nviews, 
     if (const char* e = std::getenv("CCALIB_NO_RETRY_AHEAD")) s->retry_enabled = std::atoi(e) == 0;
     if (const char* e = std::getenv("CCALIB_DUAL_BACKSUB")) s->dual_backsub = std::atoi(e) != 0;
     if (const char* e = std::getenv("CCALIB_FOLD_COMPOSE")) s->fold_compose = std::atoi(e) != 0;
+    if (const char* e = std::getenv("CCALIB_DIRECT_SUMS")) s->direct_sums = std::atoi(e) != 0;
     if (const char* e = std::getenv("CCALIB_SPLIT_PUBLISH")) s->split_publish = std::atoi(e) != 0;
     s->segs.nseg = 0;
     HIP_TRY(hipStreamSynchronize(s->stream));

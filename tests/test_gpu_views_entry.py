@@ -150,6 +150,33 @@ def test_doomed_trial_beside_its_retry_changes_nothing(pkg, monkeypatch):
         assert np.array_equal(np.asarray(a[0][k]), np.asarray(b[0][k])), k
 
 
+def test_sums_sent_by_every_workgroup_itself_change_nothing(pkg, monkeypatch):
+    """Passes with fewer than 256 sums reach the host as {sum, sum XOR pass number} pairs written by each column-sum
+    workgroup; the flag paths (one burst from the last workgroup or a publishing kernel) must hold the same bits.  Two
+    calls in a row per mode, so the second one reads pinned blocks that still hold the first one's pairs; the stereo
+    run mixes both ways inside one call (499 sums of its Jacobian pass with a flag, residual passes without)."""
+    cc, synth = pkg, pkg.synth
+    obj = synth.chessboard(9, 6, 25.0)
+    ms = synth.make_views(obj, 1500, 0xC0FFEE + 51)
+    st = synth.make_stereo(obj, 1200, 0xC0FFEE + 52)
+    K1 = cc.init_camera_matrix_2d(obj, st.img1, SIZE)
+    K2 = cc.init_camera_matrix_2d(obj, st.img2, SIZE)
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("CCALIB_DIRECT_SUMS", mode)
+        mono = [cc.calibrate_camera(obj, ms.img, SIZE) for _ in range(2)]
+        mono_trace = cc.last_lm_trace()
+        stereo = cc.stereo_calibrate(obj, st.img1, st.img2, K1, None, K2, None, SIZE, cc.CALIB_USE_INTRINSIC_GUESS,
+                                     criteria=(3, 40, 1e-9))
+        runs[mode] = (mono, mono_trace, stereo, cc.last_lm_trace())
+    a, b = runs["1"], runs["0"]
+    _same(a[0][1], a[0][0])
+    _same(a[0][0], b[0][0])
+    assert np.array_equal(a[1][:, :7], b[1][:, :7]) and np.array_equal(a[3][:, :7], b[3][:, :7])
+    for k in ("rms", "K1", "K2", "d1", "d2", "R", "T", "rt"):
+        assert np.array_equal(np.asarray(a[2][k]), np.asarray(b[2][k])), k
+
+
 def test_poses_come_back_whole_when_they_take_several_staging_rounds(pkg):
     """400 000 views: the refined poses (19 MB) leave the device in two rounds through the pinned staging buffers and are
     split into rvecs / tvecs on the way; the solver-level download of the same run must hold the same numbers."""
