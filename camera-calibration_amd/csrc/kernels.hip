@@ -763,9 +763,12 @@ __global__ __launch_bounds__(kBlock * TPB, TPB == 1 ? 3 : 1) void k_jac_fused(Pa
 // sum W V'^-1 W^T over its 64 views (NC(NC+1)/2 values) followed by sum W V'^-1 ge (NC values).
 template <int NC>
 __global__ __launch_bounds__(64) void k_schur(const double* blk, int npad, int nviews, double lambda, double* part,
-                                              const LmCtrl* __restrict__ ctrl) {
+                                              const LmCtrl* __restrict__ ctrl, double lambda_y1, double* part_y1) {
     constexpr int NS = NC * (NC + 1) / 2 + NC, NB = 27 + 6 * NC;
     if (ctrl && !ctrl->go) return;
+    // a launch for two dampings: the second half of the grid (blockIdx.y = 1) takes the other one.  Small problems
+    // pay a launch and the gap in front of it (4.7 + 4.6 us at 20 views) instead of a few more workgroups.
+    if (blockIdx.y) lambda = lambda_y1, part = part_y1;
     int v = blockIdx.x * 64 + threadIdx.x;
     bool live = v < nviews;
     int vv = live ? v : nviews - 1;
@@ -1008,8 +1011,9 @@ static void launch_jac_fused(const PassArgs& a, const CamParams& cp, const doubl
 }
 template <int NC>
 static void launch_schur(const double* blk, int npad, int nviews, double lambda, double* part, hipStream_t st,
-                         const LmCtrl* ctrl) {
-    hipLaunchKernelGGL(k_schur<NC>, dim3((nviews + 63) / 64), dim3(64), 0, st, blk, npad, nviews, lambda, part, ctrl);
+                         const LmCtrl* ctrl, double lambda2, double* part2) {
+    hipLaunchKernelGGL(k_schur<NC>, dim3((nviews + 63) / 64, part2 ? 2 : 1), dim3(64), 0, st, blk, npad, nviews, lambda, part, ctrl,
+                       lambda2, part2);
 }
 template <int NC>
 static void launch_backsub(const double* blk, int npad, int nviews, double lambda, const DeltaC& dc,

@@ -57,7 +57,9 @@ struct ModelOps {
     int NC, NRED_U, NBLK;
     void (*jac_shared)(const PassArgs&, const CamParams&, int grid, double* part, hipStream_t);
     void (*jac_view)(const PassArgs&, const CamParams&, int grid, double* blk, int npad, hipStream_t);
-    void (*schur)(const double* blk, int npad, int nviews, double lambda, double* part, hipStream_t, const LmCtrl* ctrl);
+    // part2 != null: the same sums for a second damping lambda2 in the same launch (second half of the grid)
+    void (*schur)(const double* blk, int npad, int nviews, double lambda, double* part, hipStream_t, const LmCtrl* ctrl,
+                  double lambda2, double* part2);
     void (*backsub)(const double* blk, int npad, int nviews, double lambda, const DeltaC&, const double* pose_prev,
                     double* pose_cur, double* part, double* pc, hipStream_t, const LmCtrl* ctrl);
     // whole Jacobian pass in one kernel (shared block partials: 4 * grid rows of NRED_U); null when the

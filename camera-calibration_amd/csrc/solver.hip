@@ -475,16 +475,21 @@ int stereo_compose(ccalib_solver* s, bool with_jac, int buf, const double* pose1
 
 // Launches the Schur-sum kernels of buffer `buf` for `lambda` and appends their column sums to the reduction
 // at `ofs`.  Layout appended: upper triangle (kc(kc+1)/2) then right-hand side (kc), kc = kernel columns.
-//   lambda2 != 0: the same sums for a second damping, appended at ofs2 (stereo: same launch, other half of the grid).
+//   lambda2 != 0: the same sums for a second damping, appended at ofs2 (same launch, other half of the grid).
 int enqueue_schur(ccalib_solver* s, int buf, double lambda, int ofs, const LmCtrl* ctrl, int lr_ofs = -1, double lambda2 = 0.,
                   int ofs2 = -1) {
     int kc = s->kcols(), nsum = kc * (kc + 1) / 2 + kc;
     if (s->ncams == 1) {
         PART_TAKE(part, s, (size_t)s->nblk64 * nsum);
-        s->ops[0]->schur(s->d_blk[0][buf], s->npad, s->nviews, lambda, part, s->stream, ctrl);
+        double* part2 = nullptr;
+        if (lambda2 != 0.) {
+            PART_TAKE(p2, s, (size_t)s->nblk64 * nsum);
+            part2 = p2;
+        }
+        s->ops[0]->schur(s->d_blk[0][buf], s->npad, s->nviews, lambda, part, s->stream, ctrl, lambda2, part2);
         int rc = queue_colsum(s, part, s->nblk64, nsum, ofs);
-        if (rc || lambda2 == 0.) return rc;
-        return enqueue_schur(s, buf, lambda2, ofs2, ctrl);
+        if (!rc && part2) rc = queue_colsum(s, part2, s->nblk64, nsum, ofs2);
+        return rc;
     }
     // stereo: one kernel takes the Schur sums and, with lr_ofs >= 0, the sums that enter the shared block through
     // the relative pose: B^T V3 B (21), B^T ge3 (6), W3 B (NC1 x 6)
