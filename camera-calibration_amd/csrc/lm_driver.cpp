@@ -104,7 +104,8 @@ void eig_sym(std::vector<double> A, int n, std::vector<double>& w, std::vector<d
 // deficient for SVD's purposes -- the eigen path decides: eigen back-substitution, dropping
 // |w| <= 2 eps sum|w| as SVD back-substitution does.
 void solve_sym_svd(const std::vector<double>& A, std::vector<double>& b, int n) {
-    if (n <= 64) {
+    static const bool eigen_only = std::getenv("CCALIB_EIGEN_SOLVE") != nullptr;  // development: never the Cholesky shortcut
+    if (n <= 64 && !eigen_only) {
         double L[64 * 64], y[64];
         if (chol_solve_checked(A.data(), b.data(), n, L, y)) return;
     }

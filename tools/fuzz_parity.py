@@ -161,6 +161,18 @@ def run(cases, seed, only=None, quiet=False):
                                           schur=True, nthreads=8)
                 print("from one starting point: rms", abs(g2["rms"] - r2["rms"]) / r2["rms"], "K", rel(g2["K"], r2["K"]), "rvec",
                       float(np.abs(g2["rvecs"] - r2["rvecs"]).max()), "iters", g2["iters"], r2["iters"])
+            if kind == "stereo":
+                # the same for a rig: both sides from the device's planar poses and median relative pose
+                sol = cc.Solver(obj, st.img1, st.img2)
+                rt0 = sol.init_poses(K1, None, cam=0)
+                sol.init_poses(K2, None, cam=1, want=False)
+                lr0 = sol.init_relative_pose()
+                sol.close()
+                g2 = cc.stereo_calibrate(obj, st.img1, st.img2, K1, None, K2, None, size, sflags, criteria=scrit, init_rt=rt0, init_lr=lr0)
+                r2 = orc.stereo_calibrate(obj, st.img1, st.img2, K1, None, K2, None, size, sflags, criteria=scrit, init_rt=rt0,
+                                          init_lr=lr0, schur=True, nthreads=8)
+                print("from one starting point: rms", abs(g2["rms"] - r2["rms"]) / r2["rms"], "K", max(rel(g2["K1"], r2["K1"]), rel(g2["K2"], r2["K2"])),
+                      "rvec", float(np.abs(g2["rt"] - r2["rt"])[:, :3].max()), "T", rel(g2["T"], r2["T"]), "iters", g2["iters"], r2["iters"])
             print("iteration, first exponent, accepted exponent, trials, sum before, sum after:  HIP | oracle")
             for i in range(max(len(got_trace), len(ref_trace))):
                 a = got_trace[i, :6] if i < len(got_trace) else None
