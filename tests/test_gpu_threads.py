@@ -26,7 +26,8 @@ def test_concurrent_calls_from_four_threads_match_sequential_ones(pkg):
         K2 = cc.init_camera_matrix_2d(obj, st.img2, SIZE)
         stereo = cc.stereo_calibrate(obj, st.img1, st.img2, K1, None, K2, None, SIZE, cc.CALIB_USE_INTRINSIC_GUESS,
                                      criteria=(3, 25, 1e-9))
-        return mono, stereo
+        reproj = cc.reprojection_error(obj, ms.img, mono["K"], mono["dist"], mono["rvecs"], mono["tvecs"])
+        return mono, stereo, reproj
 
     want = [work(*j) for j in jobs]
     for rnd in range(3):
@@ -50,3 +51,5 @@ def test_concurrent_calls_from_four_threads_match_sequential_ones(pkg):
                 assert np.array_equal(np.asarray(got[i][0][k]), np.asarray(want[i][0][k])), (rnd, i, k)
             for k in ("rms", "K1", "K2", "d1", "d2", "R", "T", "rt"):
                 assert np.array_equal(np.asarray(got[i][1][k]), np.asarray(want[i][1][k])), (rnd, i, k)
+            for a, b in zip(got[i][2], want[i][2]):   # the RMS re-check of monocular_circle.cpp:5-29
+                assert np.array_equal(np.asarray(a), np.asarray(b)), (rnd, i)
